@@ -1,0 +1,175 @@
+/*
+ * raptor_hip.h -- C ABI of the MI355X (gfx950) implementation of RAPTOR's constraint-evaluation
+ * hot path:  z -> trajectory -> fp64 inverse dynamics + d(tau)/dz -> constraint rows g / pg_pz.
+ *
+ * The reference (roahmlab/RAPTOR) has no FFI; its plug-in surface is the public-member C++ classes
+ * Trajectories / InverseDynamics / Constraints / Optimizer.  Every entry point below names the
+ * reference interface it stands in for (file:line under the reference checkout), and
+ * INTEGRATION.md shows the adapter a RAPTOR maintainer would add on top of it.
+ *
+ * Conventions
+ *   - all floating point is IEEE binary64, all indices are int (as in the reference);
+ *   - matrices handed across the boundary are ROW-MAJOR unless stated otherwise
+ *     (Optimizer::eval_jac_g emits pg_pz row-major: Optimization/src/Optimizer.cpp:480-485);
+ *   - every function returns RAPTOR_OK or an error code; raptor_last_error() gives the text.
+ *     Codes mirror the exception classes the reference throws (std::invalid_argument,
+ *     std::runtime_error), no exception ever crosses this boundary;
+ *   - "d_" pointers are device (HBM) pointers, everything else is host memory;
+ *   - objects are not thread-safe, exactly like the reference's.
+ *
+ * The same signatures are exported by the CPU oracle (oracle/liboracle.so) with the prefix
+ * oracle_ instead of raptor_ (host pointers everywhere); the parity tests call both.
+ */
+#ifndef RAPTOR_HIP_H
+#define RAPTOR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAPTOR_OK 0
+#define RAPTOR_ERR_INVALID_ARGUMENT 1 /* reference: throw std::invalid_argument */
+#define RAPTOR_ERR_RUNTIME 2          /* reference: throw std::runtime_error   */
+#define RAPTOR_ERR_HIP 3              /* a HIP runtime call failed             */
+#define RAPTOR_ERR_UNSUPPORTED 4      /* valid in the reference, not built here yet */
+
+/* Trajectories/include/Trajectories.h:17-20 (TimeDiscretization) */
+#define RAPTOR_TIME_UNIFORM 0
+#define RAPTOR_TIME_CHEBYSHEV 1
+
+/* trajectory primitives on the hot path */
+#define RAPTOR_TRAJ_ARMOUR_BEZIER 0 /* Trajectories/src/ArmourBezierCurves.cpp:44-163 */
+#define RAPTOR_TRAJ_BEZIER 1        /* Trajectories/src/BezierCurves.cpp:21-182      */
+#define RAPTOR_TRAJ_POLYNOMIAL 2    /* Trajectories/src/Polynomials.cpp:15-91 (used by the reference's ID tests) */
+
+/* what raptor_eval_batch computes: G only == Constraints::compute(z,false) (eval_g),
+ * JAC == Constraints::compute(z,true) (eval_jac_g).  */
+#define RAPTOR_EVAL_G 1u
+#define RAPTOR_EVAL_JAC 2u
+
+/*
+ * Flat rigid-body model = the fields of pinocchio::Model the hot path reads
+ * (KinematicsDynamics/src/CustomizedInverseDynamics.cpp:43-59, ForwardKinematics.cpp:70,137).
+ * Joint i here is Pinocchio joint i+1; every joint has one degree of freedom (nq == nv).
+ */
+typedef struct raptor_model_desc {
+    int nv;
+    const int* parent;         /* [nv]  model.parents[i+1]-1, -1 = universe                    */
+    const int* jtype;          /* [nv]  convertPinocchioJointType codes (Transform.cpp:5-54)   */
+    const double* placement_R; /* [nv*9] model.jointPlacements[i+1].rotation(), row-major     */
+    const double* placement_p; /* [nv*3] model.jointPlacements[i+1].translation()             */
+    const double* mass;        /* [nv]   model.inertias[i+1].mass()                           */
+    const double* lever;       /* [nv*3] model.inertias[i+1].lever()                          */
+    const double* inertia;     /* [nv*9] model.inertias[i+1].inertia().matrix(), row-major    */
+    double gravity[3];         /* model.gravity.linear()                                       */
+    const double* armature;    /* [nv] model.armature  (NULL = zeros)                          */
+    const double* damping;     /* [nv] model.damping   (NULL = zeros)                          */
+    const double* friction;    /* [nv] model.friction  (NULL = zeros)                          */
+} raptor_model_desc;
+
+/* Constructor arguments of the trajectory classes (T, N, Nact, discretisation, degree [, atp]). */
+typedef struct raptor_traj_desc {
+    int type;                /* RAPTOR_TRAJ_*                                                  */
+    int degree;              /* ignored for ARMOUR_BEZIER (fixed 5)                            */
+    double T;                /* duration                                                       */
+    int N;                   /* number of time samples                                         */
+    int time_discretization; /* RAPTOR_TIME_*                                                  */
+    int Nact;                /* actuated joints driven by the trajectory                       */
+    const double* q0;        /* [Nact] ArmourTrajectoryParameters (ARMOUR_BEZIER only)         */
+    const double* q_d0;      /* [Nact]                                                          */
+    const double* q_dd0;     /* [Nact]                                                          */
+} raptor_traj_desc;
+
+/* Arguments of KinovaOptimizer::set_parameters
+ * (Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaOptimizer.cpp:18-116). */
+typedef struct raptor_kinova_desc {
+    raptor_traj_desc traj;               /* must be ARMOUR_BEZIER with Nact == model nv == 7    */
+    int num_obstacles;
+    const double* box_center;            /* [O*3] boxCenters                                    */
+    const double* box_rpy;               /* [O*3] boxOrientation (roll,pitch,yaw)               */
+    const double* box_size;              /* [O*3] boxSize (full edge lengths)                   */
+    int include_gripper;                 /* adds spheres 17..19 on joint 7                      */
+    double collision_buffer;
+    const double* joint_limits_buffer;   /* [7] rad, NULL = 0                                   */
+    const double* velocity_limits_buffer;/* [7] rad/s, NULL = 0                                 */
+    const double* torque_limits_buffer;  /* [7] N m,  NULL = 0                                  */
+} raptor_kinova_desc;
+
+typedef struct raptor_model raptor_model;     /* opaque */
+typedef struct raptor_problem raptor_problem; /* opaque */
+
+/* Text of the last error raised on the calling thread. */
+const char* raptor_last_error(void);
+
+/* Replaces holding a pinocchio::Model (InverseDynamics ctor, InverseDynamics.cpp:5-11). */
+int raptor_model_create(const raptor_model_desc* desc, raptor_model** out);
+void raptor_model_destroy(raptor_model* model);
+
+/*
+ * Inverse-dynamics-only problem: Trajectories + InverseDynamics + TorqueLimits rows.
+ * One constraint block "torque": g[i*nv+j] = tau(i)(j), pg_pz rows = ptau_pz(i)
+ * (KinematicsDynamics/src/InverseDynamics.cpp:73-139, Constraints/src/TorqueLimits.cpp:18-43).
+ * Mirrors how the reference's own TestInverseDynamics drives the class
+ * (Tests/KinematicsDynamics/TestInverseDynamics.cpp:13-46).
+ */
+int raptor_id_problem_create(const raptor_model* model, const raptor_traj_desc* traj, raptor_problem** out);
+
+/* KinovaOptimizer::set_parameters: blocks [joint limits | velocity limits | torque limits | obstacles]
+ * (KinovaOptimizer.cpp:82-109). */
+int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_desc* desc, raptor_problem** out);
+
+void raptor_problem_destroy(raptor_problem* problem);
+
+/* Optimizer::get_nlp_info (KinovaOptimizer.cpp:121-147): n = varLength, m = sum of block sizes.
+ * block_offsets (may be NULL) receives num_blocks+1 row offsets, blocks in constraintsPtrVec_ order. */
+int raptor_problem_layout(const raptor_problem* problem, int* n, int* m, int* num_blocks, int* block_offsets);
+
+/* Constraints::compute_bounds of every block, concatenated (Optimizer::get_bounds_info). */
+int raptor_problem_bounds(const raptor_problem* problem, double* g_lb, double* g_ub);
+
+/* Trajectories::tspan (Trajectories/src/Trajectories.cpp:54-64). */
+int raptor_problem_tspan(const raptor_problem* problem, double* tspan);
+
+/*
+ * The hot path.  For each of the B decision vectors (d_Z is B x n row-major) evaluate every
+ * constraint block and write
+ *     d_G   [B x m]      g in Optimizer order            (Optimizer::eval_g,     Optimizer.cpp:361-385)
+ *     d_JAC [B x m x n]  pg_pz row-major, Optimizer order (Optimizer::eval_jac_g, Optimizer.cpp:467-486)
+ * d_G may be NULL when only JAC is wanted and vice versa; flags says what to compute.
+ * Asynchronous on hip_stream (a hipStream_t passed as void*, NULL = the default stream).
+ */
+int raptor_eval_batch(raptor_problem* problem, const double* d_Z, int B, unsigned flags,
+                      double* d_G, double* d_JAC, void* hip_stream);
+
+/* Same with host buffers (what Optimizer::eval_g / eval_jac_g hand over); copies through HBM, synchronous. */
+int raptor_eval_batch_host(raptor_problem* problem, const double* Z, int B, unsigned flags,
+                           double* G, double* JAC);
+
+/*
+ * Component views used by the parity tests, host buffers, synchronous:
+ *   Trajectories::compute -> q, q_d, q_dd  [B][N][Nact]   (Trajectories.h:71-76); any may be NULL
+ *   InverseDynamics::compute -> tau [B][N][nv], ptau_pz [B][N][nv][n] row-major (InverseDynamics.h:83-85)
+ */
+int raptor_trajectory_eval_host(raptor_problem* problem, const double* Z, int B,
+                                double* q, double* q_d, double* q_dd);
+int raptor_inverse_dynamics_eval_host(raptor_problem* problem, const double* Z, int B,
+                                      double* tau, double* ptau_pz);
+
+/*
+ * TaperedCapsuleCollision<F>::computeDistance, batched (Constraints/src/TaperedCapsuleCollision.cpp:43-289).
+ * P points to 4 endpoints x 3 coordinates (tc1_point_1, tc1_point_2, tc2_point_1, tc2_point_2) per pair,
+ * dP to the four 3 x F Jacobians (row-major, may be NULL: distance only), R to the 4 radii.
+ *   d_P [n_pairs][4][3], d_dP [n_pairs][4][3][F], d_R [n_pairs][4] -> d_dist [n_pairs], d_grad [n_pairs][F]
+ */
+int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const double* d_R,
+                                  int n_pairs, int F, double* d_dist, double* d_grad, void* hip_stream);
+int raptor_capsule_distance_batch_host(const double* P, const double* dP, const double* R,
+                                       int n_pairs, int F, double* dist, double* grad);
+
+/* Device selection for the calling process (one process per GPU): hipSetDevice + probe. */
+int raptor_init(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPTOR_HIP_H */

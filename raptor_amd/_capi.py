@@ -1,0 +1,326 @@
+"""ctypes binding of the C ABI declared in include/raptor_hip.h.
+
+``CApi(path, prefix)`` binds one shared library exporting ``<prefix>model_create`` ... .
+The product binds ``libraptor_hip.so`` with prefix ``raptor_``; the test-suite binds the CPU
+oracle (same signatures, prefix ``oracle_``) through this same class, so that parity tests make
+literally the same calls on both sides.  Nothing in this package names or loads the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+RAPTOR_OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_RUNTIME = 2
+ERR_HIP = 3
+ERR_UNSUPPORTED = 4
+
+TIME_UNIFORM = 0
+TIME_CHEBYSHEV = 1
+TRAJ_ARMOUR_BEZIER = 0
+TRAJ_BEZIER = 1
+TRAJ_POLYNOMIAL = 2
+EVAL_G = 1
+EVAL_JAC = 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("nv", C.c_int),
+        ("parent", _ip),
+        ("jtype", _ip),
+        ("placement_R", _dp),
+        ("placement_p", _dp),
+        ("mass", _dp),
+        ("lever", _dp),
+        ("inertia", _dp),
+        ("gravity", C.c_double * 3),
+        ("armature", _dp),
+        ("damping", _dp),
+        ("friction", _dp),
+    ]
+
+
+class TrajDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int),
+        ("degree", C.c_int),
+        ("T", C.c_double),
+        ("N", C.c_int),
+        ("time_discretization", C.c_int),
+        ("Nact", C.c_int),
+        ("q0", _dp),
+        ("q_d0", _dp),
+        ("q_dd0", _dp),
+    ]
+
+
+class KinovaDesc(C.Structure):
+    _fields_ = [
+        ("traj", TrajDesc),
+        ("num_obstacles", C.c_int),
+        ("box_center", _dp),
+        ("box_rpy", _dp),
+        ("box_size", _dp),
+        ("include_gripper", C.c_int),
+        ("collision_buffer", C.c_double),
+        ("joint_limits_buffer", _dp),
+        ("velocity_limits_buffer", _dp),
+        ("torque_limits_buffer", _dp),
+    ]
+
+
+class RaptorError(RuntimeError):
+    """Raised for RAPTOR_ERR_RUNTIME / HIP / UNSUPPORTED (reference: std::runtime_error)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[raptor error {code}] {msg}")
+        self.code = code
+
+
+class RaptorInvalidArgument(ValueError):
+    """Raised for RAPTOR_ERR_INVALID_ARGUMENT (reference: std::invalid_argument)."""
+
+    def __init__(self, msg: str):
+        super().__init__(msg)
+        self.code = ERR_INVALID_ARGUMENT
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        arr = arr.reshape(shape)
+    return arr
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_dp)
+
+
+EXPORTS = [
+    "last_error", "model_create", "model_destroy", "id_problem_create", "kinova_problem_create",
+    "problem_destroy", "problem_layout", "problem_bounds", "problem_tspan", "eval_batch",
+    "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
+    "capsule_distance_batch", "capsule_distance_batch_host", "init",
+]
+
+
+class CApi:
+    def __init__(self, path: str, prefix: str = "raptor_"):
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        L = self.lib
+        f = lambda n: getattr(L, prefix + n)  # noqa: E731
+        vp = C.c_void_p
+        f("last_error").restype = C.c_char_p
+        f("last_error").argtypes = []
+        f("model_create").argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
+        f("model_destroy").argtypes = [vp]
+        f("model_destroy").restype = None
+        f("id_problem_create").argtypes = [vp, C.POINTER(TrajDesc), C.POINTER(vp)]
+        f("kinova_problem_create").argtypes = [vp, C.POINTER(KinovaDesc), C.POINTER(vp)]
+        f("problem_destroy").argtypes = [vp]
+        f("problem_destroy").restype = None
+        f("problem_layout").argtypes = [vp, _ip, _ip, _ip, _ip]
+        f("problem_bounds").argtypes = [vp, _dp, _dp]
+        f("problem_tspan").argtypes = [vp, _dp]
+        f("eval_batch").argtypes = [vp, vp, C.c_int, C.c_uint, vp, vp, vp]
+        f("eval_batch_host").argtypes = [vp, _dp, C.c_int, C.c_uint, _dp, _dp]
+        f("trajectory_eval_host").argtypes = [vp, _dp, C.c_int, _dp, _dp, _dp]
+        f("inverse_dynamics_eval_host").argtypes = [vp, _dp, C.c_int, _dp, _dp]
+        f("capsule_distance_batch").argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        f("capsule_distance_batch_host").argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
+        f("init").argtypes = [C.c_int]
+        self._f = f
+
+    # -- helpers -------------------------------------------------------------------------
+    def fn(self, name: str):
+        return self._f(name)
+
+    def check(self, code: int) -> None:
+        if code == RAPTOR_OK:
+            return
+        msg = (self._f("last_error")() or b"").decode("utf-8", "replace")
+        if code == ERR_INVALID_ARGUMENT:
+            raise RaptorInvalidArgument(msg)
+        raise RaptorError(code, msg)
+
+    def init(self, device: int = 0) -> None:
+        self.check(self._f("init")(device))
+
+    # -- model ---------------------------------------------------------------------------
+    def model_create(self, model) -> "ModelHandle":
+        return ModelHandle(self, model)
+
+    def capsule_distance_host(self, P, dP, R):
+        P = _f64(P).reshape(-1, 4, 3)
+        n = P.shape[0]
+        R = _f64(R).reshape(n, 4)
+        dist = np.empty(n)
+        if dP is not None:
+            dP = _f64(dP)
+            F = dP.size // (n * 12) if n else 0
+            dP = dP.reshape(n, 4, 3, F)
+            grad = np.empty((n, F))
+            self.check(self._f("capsule_distance_batch_host")(_ptr(P), _ptr(dP), _ptr(R), n, F, _ptr(dist), _ptr(grad)))
+            return dist, grad
+        self.check(self._f("capsule_distance_batch_host")(_ptr(P), None, _ptr(R), n, 0, _ptr(dist), None))
+        return dist, None
+
+
+class ModelHandle:
+    def __init__(self, api: CApi, model):
+        self.api = api
+        self.nv = int(model.nv)
+        # keep the arrays alive for the duration of the call only; the library copies them
+        keep = dict(
+            parent=np.ascontiguousarray(model.parent, dtype=np.int32),
+            jtype=np.ascontiguousarray(model.jtype, dtype=np.int32),
+            placement_R=_f64(model.placement_R),
+            placement_p=_f64(model.placement_p),
+            mass=_f64(model.mass),
+            lever=_f64(model.lever),
+            inertia=_f64(model.inertia),
+            armature=_f64(model.armature),
+            damping=_f64(model.damping),
+            friction=_f64(model.friction),
+        )
+        d = ModelDesc()
+        d.nv = self.nv
+        d.parent = keep["parent"].ctypes.data_as(_ip)
+        d.jtype = keep["jtype"].ctypes.data_as(_ip)
+        for k in ("placement_R", "placement_p", "mass", "lever", "inertia", "armature", "damping", "friction"):
+            setattr(d, k, _ptr(keep[k]))
+        d.gravity = (C.c_double * 3)(*[float(x) for x in model.gravity])
+        h = C.c_void_p()
+        api.check(api.fn("model_create")(C.byref(d), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.api.fn("model_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_traj_desc(keep: list, type: int, T: float, N: int, Nact: int, degree: int = 5,
+                   time_discretization: int = TIME_CHEBYSHEV, q0=None, q_d0=None, q_dd0=None) -> TrajDesc:
+    t = TrajDesc()
+    t.type, t.degree, t.T, t.N, t.time_discretization, t.Nact = type, degree, T, N, time_discretization, Nact
+    for name, val in (("q0", q0), ("q_d0", q_d0), ("q_dd0", q_dd0)):
+        if val is not None:
+            arr = _f64(val)
+            keep.append(arr)
+            setattr(t, name, _ptr(arr))
+    return t
+
+
+class ProblemHandle:
+    """Owns a raptor_problem*; exposes layout/bounds and the evaluation entry points."""
+
+    def __init__(self, api: CApi, handle: C.c_void_p):
+        self.api = api
+        self.handle = handle
+        n, m, nb = C.c_int(), C.c_int(), C.c_int()
+        api.check(api.fn("problem_layout")(handle, C.byref(n), C.byref(m), C.byref(nb), None))
+        self.n, self.m, self.num_blocks = n.value, m.value, nb.value
+        offs = (C.c_int * (self.num_blocks + 1))()
+        api.check(api.fn("problem_layout")(handle, None, None, None, offs))
+        self.block_offsets = list(offs)
+
+    @classmethod
+    def inverse_dynamics(cls, api: CApi, model: ModelHandle, traj: TrajDesc) -> "ProblemHandle":
+        h = C.c_void_p()
+        api.check(api.fn("id_problem_create")(model.handle, C.byref(traj), C.byref(h)))
+        return cls(api, h)
+
+    @classmethod
+    def kinova(cls, api: CApi, model: ModelHandle, traj: TrajDesc, box_center, box_rpy, box_size,
+               include_gripper: bool = False, collision_buffer: float = 0.0,
+               joint_limits_buffer=None, velocity_limits_buffer=None, torque_limits_buffer=None) -> "ProblemHandle":
+        d = KinovaDesc()
+        d.traj = traj
+        bc = _f64(box_center).reshape(-1, 3)
+        br = _f64(box_rpy).reshape(-1, 3)
+        bs = _f64(box_size).reshape(-1, 3)
+        if not (bc.shape == br.shape == bs.shape):
+            raise RaptorInvalidArgument("boxCenters, boxOrientation, and boxSize should have the same size")
+        d.num_obstacles = bc.shape[0]
+        d.box_center, d.box_rpy, d.box_size = _ptr(bc), _ptr(br), _ptr(bs)
+        d.include_gripper = int(bool(include_gripper))
+        d.collision_buffer = float(collision_buffer)
+        keep = []
+        for name, val in (("joint_limits_buffer", joint_limits_buffer),
+                          ("velocity_limits_buffer", velocity_limits_buffer),
+                          ("torque_limits_buffer", torque_limits_buffer)):
+            if val is not None:
+                arr = _f64(val)
+                keep.append(arr)
+                setattr(d, name, _ptr(arr))
+        h = C.c_void_p()
+        api.check(api.fn("kinova_problem_create")(model.handle, C.byref(d), C.byref(h)))
+        return cls(api, h)
+
+    # -- queries ---------------------------------------------------------------------------
+    def bounds(self):
+        lb, ub = np.empty(self.m), np.empty(self.m)
+        self.api.check(self.api.fn("problem_bounds")(self.handle, _ptr(lb), _ptr(ub)))
+        return lb, ub
+
+    def tspan(self, N: int):
+        t = np.empty(N)
+        self.api.check(self.api.fn("problem_tspan")(self.handle, _ptr(t)))
+        return t
+
+    # -- evaluation ------------------------------------------------------------------------
+    def eval_host(self, Z, flags: int = EVAL_G | EVAL_JAC):
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        G = np.empty((B, self.m)) if flags & EVAL_G else None
+        J = np.empty((B, self.m, self.n)) if flags & EVAL_JAC else None
+        self.api.check(self.api.fn("eval_batch_host")(self.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J)))
+        return G, J
+
+    def eval_device(self, d_Z: int, B: int, flags: int, d_G: int, d_JAC: int, stream: int = 0) -> None:
+        """Raw device pointers (ints), asynchronous on ``stream``."""
+        self.api.check(self.api.fn("eval_batch")(self.handle, d_Z, B, flags, d_G or None, d_JAC or None, stream or None))
+
+    def trajectory_host(self, Z, N: int, Nact: int):
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        q, qd, qdd = (np.empty((B, N, Nact)) for _ in range(3))
+        self.api.check(self.api.fn("trajectory_eval_host")(self.handle, _ptr(Z), B, _ptr(q), _ptr(qd), _ptr(qdd)))
+        return q, qd, qdd
+
+    def inverse_dynamics_host(self, Z, N: int, nv: int, derivatives: bool = True):
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        tau = np.empty((B, N, nv))
+        ptau = np.empty((B, N, nv, self.n)) if derivatives else None
+        self.api.check(self.api.fn("inverse_dynamics_eval_host")(self.handle, _ptr(Z), B, _ptr(tau), _ptr(ptau)))
+        return tau, ptau
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.api.fn("problem_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

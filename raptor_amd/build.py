@@ -1,0 +1,45 @@
+"""Builds libraptor_hip.so (gfx950) in-tree with hipcc.  `python -m raptor_amd.build`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libraptor_hip.so")
+SOURCES = ["raptor_hip.hip"]
+HEADERS = ["kernels.h", "capsule_kernel.h", "spatial_dev.h", "device_types.h", os.path.join("..", "..", "include", "raptor_hip.h")]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + [
+        os.path.join(CSRC, s) for s in SOURCES
+    ]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(LIB)

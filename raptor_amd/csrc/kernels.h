@@ -1,0 +1,384 @@
+// gfx950 kernels of the hot path.  Included once by raptor_hip.hip.
+//
+//   K_id   (id_kernel)          one lane per (decision vector b, time sample i, column c of z):
+//                               trajectory -> world-frame RNEA -> directional derivative along column c
+//                               -> TorqueLimits rows (+ JointLimits / VelocityLimits rows).
+//   K_obs  (kinova_obs_kernel)  one lane per (b, i, collision sphere): chain FK -> sphere centre and
+//                               its Jacobian -> min signed distance over the boxes -> gradient row.
+//   K_traj (traj_kernel)        q, q_d, q_dd only (component view for the parity tests).
+//
+// Why a column per lane.  d(tau)/dz is needed for every column of z.  For the trajectories on this path a
+// column touches ONE joint (ArmourBezierCurves.cpp:147-151: diagonal; BezierCurves.cpp:165-169: block row),
+// so the column's contribution is a single directional derivative of RNEA along
+// (dq, dv, da) = (w0, w1, w2) * e_joint.  That replaces the reference's three dense nv x nv Jacobians and
+// three GEMMs (InverseDynamics.cpp:106-139) by one forward-mode sweep per lane, with no intermediate
+// matrices in memory; consecutive lanes hold consecutive columns, so the stores of one Jacobian row are
+// contiguous.  fp64 throughout.
+#ifndef RAPTOR_KERNELS_H
+#define RAPTOR_KERNELS_H
+
+#include "../../include/raptor_hip.h"
+#include "device_types.h"
+#include "spatial_dev.h"
+
+#define RAPTOR_BLOCK 256
+
+// Utils::sign (Utils/include/Utils.h:85-95)
+RD double sign_eps(double v) { return v > 1e-8 ? 1.0 : (v < -1e-8 ? -1.0 : 0.0); }
+
+// ---------------------------------------------------------------------------------------------
+// trajectory: q, q_d, q_dd of joint j at sample i   (coefficients^T * B, BezierCurves.cpp:143-145)
+// ---------------------------------------------------------------------------------------------
+RD void traj_joint(const DevTraj* __restrict__ T, const double* __restrict__ basis, const double* __restrict__ z,
+                   int i, int j, double& q, double& qd, double& qdd) {
+    const int K = T->degree + 1;
+    const double* B0 = basis + (size_t)(i * 3) * K;
+    const double* B1 = B0 + K;
+    const double* B2 = B1 + K;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (T->type == RAPTOR_TRAJ_ARMOUR_BEZIER) {
+        const double qf = T->armour_q0[j] + z[j];  // ArmourBezierCurves.cpp:96-99
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double ck = (k < 3) ? T->armour_c[k][j] : qf;
+            s0 += ck * B0[k];
+            s1 += ck * B1[k];
+            s2 += ck * B2[k];
+        }
+    } else {
+        const double* zj = z + j * K;  // column-major reshape (Utils.h:142-146)
+        for (int k = 0; k < K; k++) {
+            const double ck = zj[k];
+            s0 += ck * B0[k];
+            s1 += ck * B1[k];
+            s2 += ck * B2[k];
+        }
+    }
+    q = s0;
+    qd = s1;
+    qdd = s2;
+}
+
+// which joint column c of z drives, and with what weights (pq_pz, pq_d_pz, pq_dd_pz entries)
+RD void column_direction(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                         const double* __restrict__ wsum, int i, int c, int& jd, double& w0, double& w1, double& w2) {
+    if (T->type == RAPTOR_TRAJ_ARMOUR_BEZIER) {
+        jd = c;
+        w0 = wsum[i * 3];
+        w1 = wsum[i * 3 + 1];
+        w2 = wsum[i * 3 + 2];
+    } else {
+        const int K = T->degree + 1;
+        jd = c / K;
+        const int k = c - jd * K;
+        const double* B0 = basis + (size_t)(i * 3) * K;
+        w0 = B0[k];
+        w1 = B0[K + k];
+        w2 = B0[2 * K + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_id : serial-chain models (parent[i] == i-1), NV compile-time so that all per-link state stays in VGPRs
+// ---------------------------------------------------------------------------------------------
+template <int NV, bool DERIV>
+__global__ __launch_bounds__(RAPTOR_BLOCK) void id_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+                                                           const double* __restrict__ basis,
+                                                           const double* __restrict__ wsum, const DevLayout L,
+                                                           const double* __restrict__ Z, const long long total,
+                                                           double* __restrict__ G, double* __restrict__ JAC) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int V = L.n;
+    const int N = T->N;
+    const int c = DERIV ? (int)(w % V) : 0;
+    const long long e = DERIV ? w / V : w;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    const double* z = Z + b * V;
+
+    double q[NV], qd[NV], qdd[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) traj_joint(T, basis, z, i, j, q[j], qd[j], qdd[j]);
+
+    int jd = -1;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    if (DERIV) column_direction(T, basis, wsum, i, c, jd, w0, w1, w2);
+
+    // ---- forward sweep (world frame) ----
+    SV s_[NV], f_[NV], df_[NV];
+    M3 Rw;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 ow = v3(0, 0, 0);
+    SV v = sv_zero();
+    SV a = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};  // -a_grav
+    SV dv = sv_zero(), da = sv_zero(), Delta = sv_zero();
+
+#pragma unroll
+    for (int l = 0; l < NV; l++) {
+        const M3 A = mul(Rw, M->plR[l]);
+        V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+        double sq, cq;
+        sincos(q[l], &sq, &cq);
+        M3 R;
+        SV s;
+        joint_world(M->jtype[l], q[l], cq, sq, A, R, o, s);
+
+        const SV sqd = s * qd[l];
+        const SV vi = v + sqd;
+        const SV ai = a + s * qdd[l] + crm(v, sqd);
+        Inertia I;
+        I.mass = M->mass[l];
+        I.c = o + mul(R, v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]));
+        rotate_inertia(R, M->Ic[l], I);
+        const SV h = apply(I, vi);
+        const SV g = apply(I, ai);
+        f_[l] = g + crf(vi, h);
+        s_[l] = s;
+
+        if (DERIV) {
+            const bool isk = (l == jd);
+            if (isk) Delta = s * w0;
+            const SV ds = crm(Delta, s);  // zero up to and including the driven joint
+            const double dqd = isk ? w1 : 0.0, dqdd = isk ? w2 : 0.0;
+            const SV dsqd = ds * qd[l] + s * dqd;
+            const SV dvi = dv + dsqd;
+            const SV dai = da + ds * qdd[l] + s * dqdd + crm(dv, sqd) + crm(v, dsqd);
+            const SV dpv = dvi - crm(Delta, vi);  // derivative as seen in the moving body
+            const SV dpa = dai - crm(Delta, ai);
+            df_[l] = crf(Delta, g) + apply(I, dpa) + crf(dvi, h) + crf(vi, crf(Delta, h) + apply(I, dpv));
+            dv = dvi;
+            da = dai;
+        }
+        v = vi;
+        a = ai;
+        Rw = R;
+        ow = o;
+    }
+
+    // ---- backward sweep: suffix sums of wrenches, no transforms needed in the world frame ----
+    const size_t rowbase = (size_t)b * L.m;
+    SV F = sv_zero(), dF = sv_zero();
+#pragma unroll
+    for (int l = NV - 1; l >= 0; l--) {
+        F = F + f_[l];
+        // InverseDynamics.cpp:115-121 (damping, friction) and armature inside pinocchio::rnea (>= 3)
+        const double tau = dot(s_[l], F) + M->armature[l] * qdd[l] + M->damping[l] * qd[l] + M->friction[l] * sign_eps(qd[l]);
+        const size_t row = rowbase + L.off_tau + (size_t)i * NV + l;
+        if (DERIV) {
+            dF = dF + df_[l];
+            double dtau = dot(s_[l], dF);
+            if (l > jd) dtau += dot(crm(Delta, s_[l]), F);
+            if (l == jd) dtau += M->armature[l] * w2 + M->damping[l] * w1;
+            JAC[row * V + c] = dtau;
+        }
+        if (c == 0 && G != nullptr) G[row] = tau;
+    }
+
+    // ---- JointLimits / VelocityLimits rows (JointLimits.cpp:32-45, VelocityLimits.cpp:32-44) ----
+    if (L.off_q >= 0) {
+#pragma unroll
+        for (int l = 0; l < NV; l++) {
+            const size_t row = rowbase + L.off_q + (size_t)i * NV + l;
+            if (DERIV) JAC[row * V + c] = (l == jd) ? w0 : 0.0;
+            if (c == 0 && G != nullptr) G[row] = q[l];
+        }
+    }
+    if (L.off_qd >= 0) {
+#pragma unroll
+        for (int l = 0; l < NV; l++) {
+            const size_t row = rowbase + L.off_qd + (size_t)i * NV + l;
+            if (DERIV) JAC[row * V + c] = (l == jd) ? w1 : 0.0;
+            if (c == 0 && G != nullptr) G[row] = qd[l];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_obs : KinovaCustomizedConstraints::compute (KinovaCustomizedConstraints.cpp:73-158) with
+//         BoxCollisionAvoidance::computeDistance (BoxCollisionAvoidance.cpp:92-204, 290-373)
+// ---------------------------------------------------------------------------------------------
+template <int NV, bool DERIV>
+__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_obs_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+                                                                   const double* __restrict__ basis,
+                                                                   const double* __restrict__ wsum,
+                                                                   const DevSpheres* __restrict__ S,
+                                                                   const DevBox* __restrict__ boxes, const DevLayout L,
+                                                                   const double* __restrict__ Z, const long long total,
+                                                                   double* __restrict__ G, double* __restrict__ JAC) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int V = L.n;
+    const int N = T->N;
+    const int ns = S->num_spheres;
+    const int sp = (int)(w % ns);
+    const long long e = w / ns;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    const double* z = Z + b * V;
+    const size_t row = (size_t)b * L.m + L.off_obs + (size_t)i * ns + sp;
+
+    const int O = S->num_obstacles;
+    if (O == 0) {  // KinovaCustomizedConstraints.cpp:80-82: g and pg_pz keep their zero initialisation
+        if (G != nullptr) G[row] = 0.0;
+        if (DERIV)
+            for (int c = 0; c < V; c++) JAC[row * V + c] = 0.0;
+        return;
+    }
+
+    const int jid = S->joint_id[sp];  // chain = joints 0 .. jid-1
+    // forward kinematics along the chain, world frame
+    M3 Rw;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 ow = v3(0, 0, 0);
+    V3 ax_[NV], o_[NV];
+    bool rev_[NV];
+#pragma unroll
+    for (int l = 0; l < NV; l++) {
+        if (l < jid) {
+            double q, qd, qdd;
+            traj_joint(T, basis, z, i, l, q, qd, qdd);
+            const M3 A = mul(Rw, M->plR[l]);
+            V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+            double sq, cq;
+            sincos(q, &sq, &cq);
+            M3 R;
+            SV s;
+            joint_world(M->jtype[l], q, cq, sq, A, R, o, s);
+            const int aj = M->jtype[l] < 0 ? -M->jtype[l] : M->jtype[l];
+            rev_[l] = aj <= 3;
+            ax_[l] = rev_[l] ? s.a : s.l;
+            o_[l] = o;
+            Rw = R;
+            ow = o;
+        } else {
+            rev_[l] = false;
+            ax_[l] = v3(0, 0, 0);
+            o_[l] = v3(0, 0, 0);
+        }
+    }
+    const V3 point = ow + mul(Rw, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+
+    // min over obstacles; strict '<' keeps the first minimum (BoxCollisionAvoidance.cpp:305-308)
+    double minDist = 1e19;
+    int minIdx = 0;
+    for (int ob = 0; ob < O; ob++) {
+        const DevBox* __restrict__ bx = boxes + ob;
+        M3 R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.m[k] = bx->R[k];
+        const V3 ctr = v3(bx->center[0], bx->center[1], bx->center[2]);
+        const V3 lp = mulT(R, point - ctr);
+        const double lpv[3] = {lp.x, lp.y, lp.z};
+        double lc[3], dface[3][2];
+        double isInside = -1.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double hs = bx->size[k] / 2.0;
+            dface[k][0] = lpv[k] + hs;
+            dface[k][1] = hs - lpv[k];
+            lc[k] = fmax(-hs, fmin(lpv[k], hs));
+            if (lc[k] != lpv[k]) isInside = 1.0;
+        }
+        if (isInside == -1.0) {  // point inside the box: snap to the nearest face (:112-131)
+            double md = 1e19;
+            int face = 0, dir = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
+                if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k == face) lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0;
+        }
+        const V3 closest = mul(R, v3(lc[0], lc[1], lc[2])) + ctr;
+        const V3 diff = point - closest;
+        const double d2 = dot(diff, diff);
+        const double dist = (d2 > 1e-12) ? isInside * sqrt(d2) : 0.0;  // SQUARE_ROOT_THRESHOLD
+        if (dist < minDist) {
+            minDist = dist;
+            minIdx = ob;
+        }
+    }
+    if (G != nullptr) G[row] = minDist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
+
+    if (DERIV) {
+        // recompute the closest-point difference for the arg-min box with derivative bookkeeping (:139-204, :359-372)
+        const DevBox* __restrict__ bx = boxes + minIdx;
+        M3 R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.m[k] = bx->R[k];
+        const V3 ctr = v3(bx->center[0], bx->center[1], bx->center[2]);
+        const V3 lp = mulT(R, point - ctr);
+        const double lpv[3] = {lp.x, lp.y, lp.z};
+        double lc[3], dface[3][2], keep[3];
+        double isInside = -1.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double hs = bx->size[k] / 2.0;
+            dface[k][0] = lpv[k] + hs;
+            dface[k][1] = hs - lpv[k];
+            if (lpv[k] < -hs) { lc[k] = -hs; isInside = 1.0; keep[k] = 0.0; }
+            else if (lpv[k] > hs) { lc[k] = hs; isInside = 1.0; keep[k] = 0.0; }
+            else { lc[k] = lpv[k]; keep[k] = 1.0; }
+        }
+        if (isInside == -1.0) {
+            double md = 1e19;
+            int face = 0, dir = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
+                if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k == face) { lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0; keep[k] = 0.0; }
+        }
+        const V3 closest = mul(R, v3(lc[0], lc[1], lc[2])) + ctr;
+        const V3 diff = point - closest;
+        const double d2 = dot(diff, diff);
+        const bool ok = d2 > 1e-12;
+        const double scale = ok ? isInside / sqrt(d2) : 0.0;
+        // pg_pz row: column c = d(centre)/dq_c * pq_pz(c,c); ArmourBezier: pq_pz = w0 * I
+        const double w0 = wsum[i * 3];
+#pragma unroll
+        for (int l = 0; l < NV; l++) {
+            double gcol = 0.0;
+            if (l < jid) {
+                // ForwardKinematics.cpp:330-341: dTdq[l].p
+                const V3 pc = (rev_[l] ? cross(ax_[l], point - o_[l]) : ax_[l]) * w0;
+                V3 pl = mulT(R, pc);
+                pl = v3(pl.x * keep[0], pl.y * keep[1], pl.z * keep[2]);
+                const V3 pdiff = pc - mul(R, pl);
+                gcol = scale * dot(diff, pdiff);
+            }
+            JAC[row * V + l] = gcol;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_traj : Trajectories::compute values only
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RAPTOR_BLOCK) void traj_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                                                             const double* __restrict__ Z, const long long total,
+                                                             double* __restrict__ q, double* __restrict__ qd,
+                                                             double* __restrict__ qdd) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int Nact = T->Nact;
+    const int j = (int)(w % Nact);
+    const long long e = w / Nact;
+    const int i = (int)(e % T->N);
+    const long long b = e / T->N;
+    double a0, a1, a2;
+    traj_joint(T, basis, Z + b * T->varLength, i, j, a0, a1, a2);
+    if (q) q[w] = a0;
+    if (qd) qd[w] = a1;
+    if (qdd) qdd[w] = a2;
+}
+
+#endif

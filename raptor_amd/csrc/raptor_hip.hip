@@ -1,0 +1,589 @@
+// libraptor_hip.so -- C ABI (include/raptor_hip.h) over the gfx950 kernels in kernels.h.
+// Host side only does set-up (constant tables, layout, bounds) and launches; there is NO CPU fallback:
+// every evaluation entry point runs on the GPU or returns RAPTOR_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "capsule_kernel.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct hip_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct unsupported_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                               \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            throw hip_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));                \
+    } while (0)
+
+#define API_TRY try {
+#define API_CATCH                                   \
+    }                                               \
+    catch (const std::invalid_argument& e) {        \
+        g_err = e.what();                           \
+        return RAPTOR_ERR_INVALID_ARGUMENT;         \
+    }                                               \
+    catch (const hip_error& e) {                    \
+        g_err = e.what();                           \
+        return RAPTOR_ERR_HIP;                      \
+    }                                               \
+    catch (const unsupported_error& e) {            \
+        g_err = e.what();                           \
+        return RAPTOR_ERR_UNSUPPORTED;              \
+    }                                               \
+    catch (const std::exception& e) {               \
+        g_err = e.what();                           \
+        return RAPTOR_ERR_RUNTIME;                  \
+    }                                               \
+    return RAPTOR_OK;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t count = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void ensure(size_t n) {
+        if (n <= count) return;
+        release();
+        HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+        count = n;
+    }
+    void upload(const T* src, size_t n) {
+        ensure(n);
+        HIP_CHECK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+inline double deg2rad(double d) { return d * M_PI / 180.0; }  // Utils.h:17-19
+
+}  // namespace
+
+struct raptor_model {
+    DevModel h;  // host copy
+};
+
+struct raptor_problem {
+    int kind = 0;  // 0: inverse dynamics only, 1: Kinova
+    DevModel hmodel;
+    DevTraj htraj;
+    DevSpheres hspheres;
+    DevLayout layout;
+    int num_blocks = 0;
+    int block_offsets[8] = {0};
+    std::vector<double> tspan, g_lb, g_ub;
+    // device-resident constants
+    DevBuf<DevModel> d_model;
+    DevBuf<DevTraj> d_traj;
+    DevBuf<double> d_basis, d_wsum;
+    DevBuf<DevSpheres> d_spheres;
+    DevBuf<DevBox> d_boxes;
+    // staging for the *_host entry points (grown on demand, reused)
+    DevBuf<double> s_Z, s_G, s_J, s_a, s_b, s_c;
+};
+
+namespace {
+
+void fill_model(const raptor_model_desc* d, DevModel& m) {
+    if (d == nullptr) throw std::invalid_argument("model: null descriptor");
+    if (d->nv <= 0) throw std::invalid_argument("model: nv must be positive");
+    if (d->nv > RAPTOR_MAX_NV) throw std::invalid_argument("model: nv exceeds RAPTOR_MAX_NV (36)");
+    if (!d->parent || !d->jtype || !d->placement_R || !d->placement_p || !d->mass || !d->lever || !d->inertia)
+        throw std::invalid_argument("model: null array");
+    std::memset(&m, 0, sizeof(m));
+    m.nv = d->nv;
+    m.serial_chain = 1;
+    for (int i = 0; i < d->nv; i++) {
+        if (d->parent[i] >= i || d->parent[i] < -1) throw std::invalid_argument("model: parents must precede children");
+        if (d->jtype[i] == 0 || std::abs(d->jtype[i]) > 6) throw std::invalid_argument("model: jtype must be +-1..6");
+        if (d->jtype[i] == -6) throw unsupported_error("model: jtype -6 is mishandled by the reference itself (Spatial.h:100-104); refusing");
+        m.parent[i] = d->parent[i];
+        if (d->parent[i] != i - 1) m.serial_chain = 0;
+        m.jtype[i] = d->jtype[i];
+        for (int k = 0; k < 9; k++) m.plR[i][k] = d->placement_R[i * 9 + k];
+        for (int k = 0; k < 3; k++) {
+            m.plp[i][k] = d->placement_p[i * 3 + k];
+            m.lever[i][k] = d->lever[i * 3 + k];
+        }
+        m.mass[i] = d->mass[i];
+        const double* I = d->inertia + i * 9;
+        m.Ic[i][0] = I[0]; m.Ic[i][1] = I[1]; m.Ic[i][2] = I[2];
+        m.Ic[i][3] = I[4]; m.Ic[i][4] = I[5]; m.Ic[i][5] = I[8];
+        m.armature[i] = d->armature ? d->armature[i] : 0.0;
+        m.damping[i] = d->damping ? d->damping[i] : 0.0;
+        m.friction[i] = d->friction ? d->friction[i] : 0.0;
+    }
+    for (int k = 0; k < 3; k++) m.neg_gravity[k] = -d->gravity[k];  // CustomizedInverseDynamics.cpp:212
+}
+
+// Trajectory constructor + per-sample basis tables (Trajectories.cpp:45-69, BezierCurves.cpp:21-37,117-141,
+// Polynomials.cpp:54-68, ArmourBezierCurves.cpp:63-69).  Pure set-up: runs once per problem.
+void fill_traj(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan, std::vector<double>& basis,
+               std::vector<double>& wsum) {
+    if (d == nullptr) throw std::invalid_argument("traj: null descriptor");
+    std::memset(&t, 0, sizeof(t));
+    if (d->N < 1 || d->Nact < 1) throw std::invalid_argument("traj: N and Nact must be positive");
+    if (d->Nact > RAPTOR_MAX_NV) throw std::invalid_argument("traj: Nact too large");
+    t.type = d->type;
+    t.N = d->N;
+    t.Nact = d->Nact;
+    const double T = d->T;
+    const int N = d->N;
+    if (d->type == RAPTOR_TRAJ_ARMOUR_BEZIER) {
+        t.degree = 5;  // ARMOUR_BEZIER_CURVE_DEGREE
+        t.varLength = d->Nact;
+        if (!d->q0) throw std::invalid_argument("ArmourBezierCurves: q0.size() != Nact");
+        if (!d->q_d0) throw std::invalid_argument("ArmourBezierCurves: q_d0.size() != Nact");
+        if (!d->q_dd0) throw std::invalid_argument("ArmourBezierCurves: q_dd0.size() != Nact");
+        for (int j = 0; j < d->Nact; j++) {
+            t.armour_q0[j] = d->q0[j];
+            t.armour_c[0][j] = d->q0[j];
+            t.armour_c[1][j] = d->q0[j] + (T * d->q_d0[j]) / 5.0;
+            t.armour_c[2][j] = d->q0[j] + (2.0 * T * d->q_d0[j]) / 5.0 + (T * T * d->q_dd0[j]) / 20.0;
+        }
+    } else if (d->type == RAPTOR_TRAJ_BEZIER || d->type == RAPTOR_TRAJ_POLYNOMIAL) {
+        if (d->degree < 1 || d->degree > RAPTOR_MAX_DEGREE) throw std::invalid_argument("traj: degree out of range");
+        t.degree = d->degree;
+        t.varLength = (d->degree + 1) * d->Nact;
+    } else {
+        throw std::invalid_argument("traj: unknown trajectory type");
+    }
+    tspan.assign(N, 0.0);
+    if (d->time_discretization == RAPTOR_TIME_UNIFORM) {
+        for (int i = 0; i < N; i++) tspan[i] = (N == 1) ? T : (0.0 + i * ((T - 0.0) / (N - 1)));
+        if (N > 1) tspan[N - 1] = T;
+    } else if (d->time_discretization == RAPTOR_TIME_CHEBYSHEV) {
+        for (int i = 1; i < N - 1; i++) tspan[i] = 0.5 * T * (1 + std::cos(M_PI * (2 * (N - i) - 3) / (2 * (N - 2))));
+        tspan[0] = 0;
+        tspan[N - 1] = T;
+    } else {
+        throw std::invalid_argument("traj: unknown time discretization");
+    }
+    const int deg = t.degree, K = deg + 1;
+    basis.assign((size_t)N * 3 * K, 0.0);
+    wsum.assign((size_t)N * 3, 0.0);
+    std::vector<double> binom(K, 1.0);
+    for (int j = 1; j <= deg / 2; j++) {
+        binom[j] = binom[j - 1] * (deg + 1 - j) / j;
+        binom[deg - j] = binom[j];
+    }
+    for (int x = 0; x < N; x++) {
+        double* B = &basis[(size_t)(x * 3) * K];
+        double* dB = B + K;
+        double* ddB = dB + K;
+        if (d->type == RAPTOR_TRAJ_POLYNOMIAL) {
+            const double tt = tspan[x];
+            B[0] = 1; dB[0] = 0; ddB[0] = 0;
+            B[1] = tt; dB[1] = 1; ddB[1] = 0;
+            double powt = 1;
+            for (int i = 2; i <= deg; i++) {
+                ddB[i] = powt;
+                dB[i] = tt * ddB[i] / (i - 1);
+                B[i] = tt * dB[i] / i;
+                powt *= tt;
+            }
+        } else {
+            const double tt = tspan[x] / T;
+            std::vector<double> tA(K, 1.0), tB(K, 1.0), dtA(K, 0.0), dtB(K, 0.0), ddtA(K, 0.0), ddtB(K, 0.0);
+            for (int j = 1; j <= deg; j++) {
+                tA[j] = tt * tA[j - 1];
+                tB[deg - j] = (1 - tt) * tB[deg - j + 1];
+                dtA[j] = j * tA[j - 1];
+                dtB[deg - j] = -j * tB[deg - j + 1];
+                ddtA[j] = j * dtA[j - 1];
+                ddtB[deg - j] = -j * dtB[deg - j + 1];
+            }
+            for (int k = 0; k < K; k++) {
+                B[k] = binom[k] * tA[k] * tB[k];
+                dB[k] = binom[k] * (dtA[k] * tB[k] + tA[k] * dtB[k]) / T;
+                ddB[k] = binom[k] * (ddtA[k] * tB[k] + 2 * dtA[k] * dtB[k] + tA[k] * ddtB[k]) / (T * T);
+            }
+        }
+        if (d->type == RAPTOR_TRAJ_ARMOUR_BEZIER) {  // ArmourBezierCurves.cpp:148-150
+            wsum[x * 3] = B[3] + B[4] + B[5];
+            wsum[x * 3 + 1] = dB[3] + dB[4] + dB[5];
+            wsum[x * 3 + 2] = ddB[3] + ddB[4] + ddB[5];
+        }
+    }
+}
+
+void upload_common(raptor_problem& p, const std::vector<double>& basis, const std::vector<double>& wsum) {
+    p.d_model.upload(&p.hmodel, 1);
+    p.d_traj.upload(&p.htraj, 1);
+    p.d_basis.upload(basis.data(), basis.size());
+    p.d_wsum.upload(wsum.data(), wsum.size());
+}
+
+inline unsigned grid_for(long long total) { return (unsigned)((total + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK); }
+
+void check_launchable(const raptor_problem& p, int B) {
+    if (B < 0) throw std::invalid_argument("B < 0");
+    const long long lanes = (long long)B * p.htraj.N * std::max(p.layout.n, p.hspheres.num_spheres);
+    if (lanes / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+}
+
+template <bool DERIV>
+void launch_id(raptor_problem& p, const DevLayout& L, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
+    const long long total = (long long)B * p.htraj.N * (DERIV ? L.n : 1);
+    if (total == 0) return;
+    if (!p.hmodel.serial_chain) throw unsupported_error("inverse dynamics kernel: only serial-chain models are built so far");
+    switch (p.hmodel.nv) {
+        case 7:
+            hipLaunchKernelGGL((id_kernel<7, DERIV>), dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p,
+                               p.d_traj.p, p.d_basis.p, p.d_wsum.p, L, dZ, total, dG, dJ);
+            break;
+        default:
+            throw unsupported_error("inverse dynamics kernel: nv = " + std::to_string(p.hmodel.nv) + " not instantiated yet");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+template <bool DERIV>
+void launch_obs(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
+    const long long total = (long long)B * p.htraj.N * p.hspheres.num_spheres;
+    if (total == 0) return;
+    hipLaunchKernelGGL((kinova_obs_kernel<7, DERIV>), dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p,
+                       p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, total, dG, dJ);
+    HIP_CHECK(hipGetLastError());
+}
+
+void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, double* dG, double* dJ, hipStream_t st) {
+    if (!(flags & (RAPTOR_EVAL_G | RAPTOR_EVAL_JAC))) throw std::invalid_argument("flags: nothing to evaluate");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && dJ == nullptr) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && dG == nullptr) throw std::invalid_argument("G buffer is null");
+    if (B > 0 && dZ == nullptr) throw std::invalid_argument("Z is null");
+    check_launchable(p, B);
+    if (B == 0) return;
+    if (!(flags & RAPTOR_EVAL_G)) dG = nullptr;
+    if (jac) {
+        launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
+        if (p.kind == 1) launch_obs<true>(p, dZ, B, dG, dJ, st);
+    } else {
+        launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
+        if (p.kind == 1) launch_obs<false>(p, dZ, B, dG, nullptr, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* raptor_last_error(void) { return g_err.c_str(); }
+
+int raptor_init(int device) {
+    API_TRY
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) throw std::invalid_argument("raptor_init: no such device");
+    HIP_CHECK(hipSetDevice(device));
+    API_CATCH
+}
+
+int raptor_model_create(const raptor_model_desc* desc, raptor_model** out) {
+    API_TRY
+    if (!out) throw std::invalid_argument("out is null");
+    std::unique_ptr<raptor_model> m(new raptor_model());
+    fill_model(desc, m->h);
+    *out = m.release();
+    API_CATCH
+}
+void raptor_model_destroy(raptor_model* m) { delete m; }
+
+int raptor_id_problem_create(const raptor_model* model, const raptor_traj_desc* traj, raptor_problem** out) {
+    API_TRY
+    if (!model || !out) throw std::invalid_argument("null argument");
+    std::unique_ptr<raptor_problem> p(new raptor_problem());
+    p->kind = 0;
+    p->hmodel = model->h;
+    std::vector<double> basis, wsum;
+    fill_traj(traj, p->htraj, p->tspan, basis, wsum);
+    if (p->htraj.Nact != p->hmodel.nv) throw std::invalid_argument("InverseDynamics: trajectory Nact must equal model nv");
+    std::memset(&p->hspheres, 0, sizeof(p->hspheres));
+    const int rows = p->htraj.N * p->htraj.Nact;
+    p->layout = DevLayout{rows, p->htraj.varLength, -1, -1, 0, -1};
+    p->num_blocks = 1;
+    p->block_offsets[0] = 0;
+    p->block_offsets[1] = rows;
+    p->g_lb.assign(rows, -1e19);
+    p->g_ub.assign(rows, 1e19);
+    upload_common(*p, basis, wsum);
+    *out = p.release();
+    API_CATCH
+}
+
+int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_desc* d, raptor_problem** out) {
+    API_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    std::unique_ptr<raptor_problem> p(new raptor_problem());
+    p->kind = 1;
+    p->hmodel = model->h;
+    if (d->traj.type != RAPTOR_TRAJ_ARMOUR_BEZIER) throw std::invalid_argument("KinovaOptimizer uses ArmourBezierCurves");
+    std::vector<double> basis, wsum;
+    fill_traj(&d->traj, p->htraj, p->tspan, basis, wsum);
+    if (p->hmodel.nv != 7 || p->htraj.Nact != 7) throw std::invalid_argument("KinovaOptimizer: NUM_JOINTS is 7");
+    if (d->num_obstacles < 0) throw std::invalid_argument("num_obstacles < 0");
+    if (d->num_obstacles > 0 && (!d->box_center || !d->box_rpy || !d->box_size))
+        throw std::invalid_argument("boxCenters, boxOrientation, and boxSize should have the same size");
+    const int N = p->htraj.N;
+
+    // sphere tables: KinovaCustomizedConstraints.h:21-54, gripper spheres KinovaCustomizedConstraints.cpp:42-47
+    static const int JID[17] = {2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4, 4, 6, 6, 7, 7, 7};
+    static const double OFF[17][3] = {
+        {0.0, -0.05, -0.01}, {0.0, -0.11, -0.01}, {0.0, -0.17, -0.01}, {0.0, -0.24, -0.01}, {0.0, -0.30, -0.01},
+        {0.0, -0.36, -0.01}, {0.0, -0.43, -0.01}, {0.0, -0.07, 0.0},   {0.0, -0.14, 0.0},   {0.0, -0.21, 0.0},
+        {0.0, -0.28, 0.0},   {0.0, -0.32, 0.0},   {0.0, -0.07, 0.0},   {0.0, -0.14, 0.0},   {-0.03, -0.06, -0.055},
+        {0.0, -0.06, -0.055}, {0.03, -0.06, -0.055}};
+    static const double RAD[17] = {0.06, 0.06, 0.06, 0.06, 0.06, 0.06, 0.07, 0.07, 0.06, 0.06, 0.06, 0.06, 0.05, 0.05, 0.02, 0.02, 0.02};
+    DevSpheres& S = p->hspheres;
+    std::memset(&S, 0, sizeof(S));
+    S.num_spheres = 17;
+    for (int s = 0; s < 17; s++) {
+        S.joint_id[s] = JID[s];
+        for (int k = 0; k < 3; k++) S.offset[s][k] = OFF[s][k];
+        S.radius[s] = RAD[s];
+    }
+    if (d->include_gripper) {
+        const double zs[3] = {-0.10, -0.15, -0.20};
+        for (int k = 0; k < 3; k++) {
+            const int s = S.num_spheres++;
+            S.joint_id[s] = 7;
+            S.offset[s][0] = 0.0; S.offset[s][1] = 0.0; S.offset[s][2] = zs[k];
+            S.radius[s] = 0.05;
+        }
+    }
+    S.num_obstacles = d->num_obstacles;
+
+    // boxes: R = Rz(yaw) Ry(pitch) Rx(roll)  (BoxCollisionAvoidance.cpp:59-61)
+    std::vector<DevBox> boxes(std::max(1, d->num_obstacles));
+    std::memset(boxes.data(), 0, boxes.size() * sizeof(DevBox));
+    for (int o = 0; o < d->num_obstacles; o++) {
+        const double* rpy = d->box_rpy + 3 * o;
+        const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]);
+        const double cp = std::cos(rpy[1]), sp = std::sin(rpy[1]);
+        const double cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+        const double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr};
+        const double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
+        const double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+        double ZY[9], R[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += Rz[3 * i + k] * Ry[3 * k + j];
+                ZY[3 * i + j] = s;
+            }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += ZY[3 * i + k] * Rx[3 * k + j];
+                R[3 * i + j] = s;
+            }
+        for (int k = 0; k < 9; k++) boxes[o].R[k] = R[k];
+        for (int k = 0; k < 3; k++) {
+            boxes[o].center[k] = d->box_center[3 * o + k];
+            boxes[o].size[k] = d->box_size[3 * o + k];
+        }
+    }
+
+    // layout, KinovaOptimizer.cpp:82-109
+    const int r7 = N * 7, rs = N * S.num_spheres;
+    p->layout = DevLayout{3 * r7 + rs, 7, 0, r7, 2 * r7, 3 * r7};
+    p->num_blocks = 4;
+    p->block_offsets[0] = 0;
+    p->block_offsets[1] = r7;
+    p->block_offsets[2] = 2 * r7;
+    p->block_offsets[3] = 3 * r7;
+    p->block_offsets[4] = 3 * r7 + rs;
+
+    // bounds, KinovaOptimizer.cpp:52-80 + KinovaConstants.h:11-27 + *Limits::compute_bounds
+    static const double JL[7] = {-1e19, -128.9, -1e19, -147.8, -1e19, -120.3, -1e19};
+    static const double JU[7] = {1e19, 128.9, 1e19, 147.8, 1e19, 120.3, 1e19};
+    static const double VL[7] = {-100, -100, -100, -100, -180, -180, -180};
+    static const double VU[7] = {100, 100, 100, 100, 180, 180, 180};
+    static const double TL[7] = {-90.0, -90.0, -90.0, -90.0, -45.0, -45.0, -45.0};
+    static const double TU[7] = {90.0, 90.0, 90.0, 90.0, 45.0, 45.0, 45.0};
+    p->g_lb.assign(p->layout.m, 0.0);
+    p->g_ub.assign(p->layout.m, 0.0);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < 7; j++) {
+            const double jb = d->joint_limits_buffer ? d->joint_limits_buffer[j] : 0.0;
+            const double vb = d->velocity_limits_buffer ? d->velocity_limits_buffer[j] : 0.0;
+            const double tb = d->torque_limits_buffer ? d->torque_limits_buffer[j] : 0.0;
+            p->g_lb[i * 7 + j] = deg2rad(JL[j]) + jb;
+            p->g_ub[i * 7 + j] = deg2rad(JU[j]) - jb;
+            p->g_lb[r7 + i * 7 + j] = deg2rad(VL[j]) + vb;
+            p->g_ub[r7 + i * 7 + j] = deg2rad(VU[j]) - vb;
+            p->g_lb[2 * r7 + i * 7 + j] = TL[j] + tb;
+            p->g_ub[2 * r7 + i * 7 + j] = TU[j] - tb;
+        }
+    for (int r = 0; r < rs; r++) {  // KinovaCustomizedConstraints.cpp:160-164
+        p->g_lb[3 * r7 + r] = d->collision_buffer;
+        p->g_ub[3 * r7 + r] = 1e19;
+    }
+
+    upload_common(*p, basis, wsum);
+    p->d_spheres.upload(&S, 1);
+    p->d_boxes.upload(boxes.data(), boxes.size());
+    *out = p.release();
+    API_CATCH
+}
+
+void raptor_problem_destroy(raptor_problem* p) { delete p; }
+
+int raptor_problem_layout(const raptor_problem* p, int* n, int* m, int* num_blocks, int* block_offsets) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (n) *n = p->layout.n;
+    if (m) *m = p->layout.m;
+    if (num_blocks) *num_blocks = p->num_blocks;
+    if (block_offsets)
+        for (int i = 0; i <= p->num_blocks; i++) block_offsets[i] = p->block_offsets[i];
+    API_CATCH
+}
+
+int raptor_problem_bounds(const raptor_problem* p, double* g_lb, double* g_ub) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (g_lb) std::memcpy(g_lb, p->g_lb.data(), p->g_lb.size() * sizeof(double));
+    if (g_ub) std::memcpy(g_ub, p->g_ub.data(), p->g_ub.size() * sizeof(double));
+    API_CATCH
+}
+
+int raptor_problem_tspan(const raptor_problem* p, double* tspan) {
+    API_TRY
+    if (!p || !tspan) throw std::invalid_argument("null argument");
+    std::memcpy(tspan, p->tspan.data(), p->tspan.size() * sizeof(double));
+    API_CATCH
+}
+
+int raptor_eval_batch(raptor_problem* p, const double* d_Z, int B, unsigned flags, double* d_G, double* d_JAC, void* stream) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    eval_device(*p, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    API_CATCH
+}
+
+int raptor_eval_batch_host(raptor_problem* p, const double* Z, int B, unsigned flags, double* G, double* JAC) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B > 0 && !Z) throw std::invalid_argument("Z is null");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0, wg = (flags & RAPTOR_EVAL_G) != 0;
+    if (jac && !JAC) throw std::invalid_argument("JAC buffer is null");
+    if (wg && !G) throw std::invalid_argument("G buffer is null");
+    if (B == 0) return RAPTOR_OK;
+    const size_t n = p->layout.n, m = p->layout.m;
+    p->s_Z.upload(Z, (size_t)B * n);
+    if (wg) p->s_G.ensure((size_t)B * m);
+    if (jac) p->s_J.ensure((size_t)B * m * n);
+    eval_device(*p, p->s_Z.p, B, flags, wg ? p->s_G.p : nullptr, jac ? p->s_J.p : nullptr, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (wg) HIP_CHECK(hipMemcpy(G, p->s_G.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac) HIP_CHECK(hipMemcpy(JAC, p->s_J.p, (size_t)B * m * n * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_trajectory_eval_host(raptor_problem* p, const double* Z, int B, double* q, double* q_d, double* q_dd) {
+    API_TRY
+    if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    const size_t tot = (size_t)B * p->htraj.N * p->htraj.Nact;
+    p->s_Z.upload(Z, (size_t)B * p->layout.n);
+    p->s_a.ensure(tot);
+    p->s_b.ensure(tot);
+    p->s_c.ensure(tot);
+    hipLaunchKernelGGL(traj_kernel, dim3(grid_for((long long)tot)), dim3(RAPTOR_BLOCK), 0, nullptr, p->d_traj.p,
+                       p->d_basis.p, p->s_Z.p, (long long)tot, p->s_a.p, p->s_b.p, p->s_c.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    if (q) HIP_CHECK(hipMemcpy(q, p->s_a.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+    if (q_d) HIP_CHECK(hipMemcpy(q_d, p->s_b.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+    if (q_dd) HIP_CHECK(hipMemcpy(q_dd, p->s_c.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_inverse_dynamics_eval_host(raptor_problem* p, const double* Z, int B, double* tau, double* ptau_pz) {
+    API_TRY
+    if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    const int nv = p->hmodel.nv, N = p->htraj.N, n = p->layout.n;
+    if (p->htraj.Nact != nv) throw std::invalid_argument("InverseDynamics: trajectory Nact must equal model nv");
+    const size_t rows = (size_t)N * nv;
+    DevLayout L{(int)rows, n, -1, -1, 0, -1};
+    p->s_Z.upload(Z, (size_t)B * n);
+    p->s_G.ensure((size_t)B * rows);
+    if (ptau_pz) {
+        p->s_J.ensure((size_t)B * rows * n);
+        launch_id<true>(*p, L, p->s_Z.p, B, p->s_G.p, p->s_J.p, nullptr);
+    } else {
+        launch_id<false>(*p, L, p->s_Z.p, B, p->s_G.p, nullptr, nullptr);
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    if (tau) HIP_CHECK(hipMemcpy(tau, p->s_G.p, (size_t)B * rows * sizeof(double), hipMemcpyDeviceToHost));
+    if (ptau_pz) HIP_CHECK(hipMemcpy(ptau_pz, p->s_J.p, (size_t)B * rows * n * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const double* d_R, int n_pairs, int F,
+                                  double* d_dist, double* d_grad, void* stream) {
+    API_TRY
+    if (n_pairs < 0 || F < 0) throw std::invalid_argument("negative size");
+    if (n_pairs == 0) return RAPTOR_OK;
+    if (!d_P || !d_R || !d_dist) throw std::invalid_argument("null argument");
+    if (d_dP && !d_grad) throw std::invalid_argument("grad buffer is null");
+    hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(n_pairs)), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_P, d_dP,
+                       d_R, n_pairs, F, d_dist, d_grad);
+    HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+int raptor_capsule_distance_batch_host(const double* P, const double* dP, const double* R, int n_pairs, int F,
+                                       double* dist, double* grad) {
+    API_TRY
+    if (n_pairs < 0 || F < 0) throw std::invalid_argument("negative size");
+    if (n_pairs == 0) return RAPTOR_OK;
+    if (!P || !R || !dist) throw std::invalid_argument("null argument");
+    if (dP && !grad) throw std::invalid_argument("grad buffer is null");
+    DevBuf<double> bP, bdP, bR, bd, bg;
+    bP.upload(P, (size_t)n_pairs * 12);
+    bR.upload(R, (size_t)n_pairs * 4);
+    bd.ensure(n_pairs);
+    if (dP) {
+        bdP.upload(dP, (size_t)n_pairs * 12 * F);
+        bg.ensure((size_t)n_pairs * std::max(F, 1));
+    }
+    hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(n_pairs)), dim3(RAPTOR_BLOCK), 0, nullptr, bP.p, dP ? bdP.p : nullptr,
+                       bR.p, n_pairs, F, bd.p, dP ? bg.p : nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(dist, bd.p, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+    if (dP && F > 0) HIP_CHECK(hipMemcpy(grad, bg.p, (size_t)n_pairs * F * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+}  // extern "C"
