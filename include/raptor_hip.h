@@ -166,6 +166,16 @@ int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const d
 int raptor_capsule_distance_batch_host(const double* P, const double* dP, const double* R,
                                        int n_pairs, int F, double* dist, double* grad);
 
+/*
+ * Per-kernel timing with HIP events recorded on the evaluation stream, for measurement harnesses
+ * (the reference keeps per-callback wall-clock counters instead: Optimization/src/Optimizer.cpp:717-754).
+ * Between _begin and _end every raptor_eval_batch records three events (before the inverse-dynamics
+ * kernel, between the kernels, after the obstacle kernel), up to max_evaluations calls; _end waits for
+ * them and returns the average duration of each kernel in milliseconds.
+ */
+int raptor_profile_begin(raptor_problem* problem, int max_evaluations);
+int raptor_profile_end(raptor_problem* problem, int* evaluations, double* id_ms_avg, double* obs_ms_avg);
+
 /* Device selection for the calling process (one process per GPU): hipSetDevice + probe. */
 int raptor_init(int device);
 

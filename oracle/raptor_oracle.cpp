@@ -1384,6 +1384,13 @@ int oracle_capsule_distance_batch(const double* P, const double* dP, const doubl
 }
 
 int oracle_init(int) { return RAPTOR_OK; }
+int oracle_profile_begin(raptor_problem*, int) { return RAPTOR_OK; }
+int oracle_profile_end(raptor_problem*, int* n, double* a, double* b) {
+    if (n) *n = 0;
+    if (a) *a = 0;
+    if (b) *b = 0;
+    return RAPTOR_OK;
+}
 
 // ---------------- oracle-only probes used to pin the oracle itself (tests/test_oracle_*.py) ----------------
 // pinocchio::rnea restatement: tau (armature included, no damping/friction) and accumulated link wrenches f[nv][6]

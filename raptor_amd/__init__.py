@@ -22,9 +22,10 @@ def api() -> "_capi.CApi":
     """The bound HIP library; fails loudly when it has not been built."""
     global _api
     if _api is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("RAPTOR_HIP_LIB", LIB_PATH)  # A/B builds of the same library
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -m raptor_amd.build` "
+                f"{path} is missing: build it with `python -m raptor_amd.build` "
                 "(the hot path has no CPU fallback)")
-        _api = _capi.CApi(LIB_PATH, "raptor_")
+        _api = _capi.CApi(path, "raptor_")
     return _api

@@ -109,7 +109,7 @@ EXPORTS = [
     "last_error", "model_create", "model_destroy", "id_problem_create", "kinova_problem_create",
     "problem_destroy", "problem_layout", "problem_bounds", "problem_tspan", "eval_batch",
     "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
-    "capsule_distance_batch", "capsule_distance_batch_host", "init",
+    "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
 ]
 
 
@@ -140,6 +140,8 @@ class CApi:
         f("capsule_distance_batch").argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
         f("capsule_distance_batch_host").argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
         f("init").argtypes = [C.c_int]
+        f("profile_begin").argtypes = [vp, C.c_int]
+        f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         self._f = f
 
     # -- helpers -------------------------------------------------------------------------
@@ -298,6 +300,14 @@ class ProblemHandle:
     def eval_device(self, d_Z: int, B: int, flags: int, d_G: int, d_JAC: int, stream: int = 0) -> None:
         """Raw device pointers (ints), asynchronous on ``stream``."""
         self.api.check(self.api.fn("eval_batch")(self.handle, d_Z, B, flags, d_G or None, d_JAC or None, stream or None))
+
+    def profile_begin(self, max_evaluations: int) -> None:
+        self.api.check(self.api.fn("profile_begin")(self.handle, max_evaluations))
+
+    def profile_end(self):
+        n, a, b = C.c_int(), C.c_double(), C.c_double()
+        self.api.check(self.api.fn("profile_end")(self.handle, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
 
     def trajectory_host(self, Z, N: int, Nact: int):
         Z = _f64(Z).reshape(-1, self.n)

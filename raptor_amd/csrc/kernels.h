@@ -79,34 +79,59 @@ RD void column_direction(const DevTraj* __restrict__ T, const double* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_id : serial-chain models (parent[i] == i-1), NV compile-time so that all per-link state stays in VGPRs
+// K_id : serial-chain models (parent[i] == i-1).
+//
+// Lane = (sample-eval e, column c).  The lanes of one e are consecutive (flat index w = e*V + c), so a
+// 256-lane block covers at most 256/V + 2 sample-evals.  Base quantities that are identical for all
+// columns of e -- the world-frame joint axis s_l, the link wrench f_l and the joint-space extras
+// (armature/damping/friction) -- are kept ONCE per e in LDS ("link-recursive sweeps staged through LDS"):
+// every lane of e computes and stores the same values (no barrier needed: a lane only ever reads back
+// what it, or a lane holding bit-identical values, has written), and reads them back as broadcasts.
+// Per-lane state is only what depends on the column: the running directional velocity/acceleration and
+// NV torque-derivative accumulators.  The link loop is rolled, so constants stream through SGPRs
+// instead of being hoisted into (and spilled from) the register file.
+//
+//   forward, link l:   s_l, v_l, a_l, I_l, f_l             (base, world frame)
+//                      Delta = s_k * w0 once l == k        (virtual displacement of the subtree of joint k)
+//                      ds_l, dv_l, da_l, df_l              (directional derivative along column c)
+//                      dtau_j += s_j . df_l   for j <= l   (immediate accumulation, replaces a df array)
+//   backward, link l:  F_l = sum_{i>=l} f_i ;  tau_l = s_l . F_l + extras
+//                      dtau_l += (Delta x s_l) . F_l  for l > k
 // ---------------------------------------------------------------------------------------------
+#define RAPTOR_ID_SLOT 13  // doubles per link in an LDS slot: s (6), f (6), extras (1)
+
+RD SV lds_sv(const double* p) { return SV{v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5])}; }
+RD void lds_put(double* p, SV x) {
+    p[0] = x.a.x; p[1] = x.a.y; p[2] = x.a.z;
+    p[3] = x.l.x; p[4] = x.l.y; p[5] = x.l.z;
+}
+
 template <int NV, bool DERIV>
-__global__ __launch_bounds__(RAPTOR_BLOCK) void id_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+__global__ __launch_bounds__(RAPTOR_BLOCK, 2) void id_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
                                                            const double* __restrict__ basis,
                                                            const double* __restrict__ wsum, const DevLayout L,
                                                            const double* __restrict__ Z, const long long total,
                                                            double* __restrict__ G, double* __restrict__ JAC) {
-    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
-    if (w >= total) return;
+    extern __shared__ double lds[];
     const int V = L.n;
+    const int lanes_per_e = DERIV ? V : 1;
+    const long long wblock = (long long)blockIdx.x * blockDim.x;
+    const long long w = wblock + threadIdx.x;
+    if (w >= total) return;
     const int N = T->N;
-    const int c = DERIV ? (int)(w % V) : 0;
-    const long long e = DERIV ? w / V : w;
+    const long long e = w / lanes_per_e;
+    const int c = DERIV ? (int)(w - e * lanes_per_e) : 0;
     const int i = (int)(e % N);
     const long long b = e / N;
     const double* z = Z + b * V;
-
-    double q[NV], qd[NV], qdd[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) traj_joint(T, basis, z, i, j, q[j], qd[j], qdd[j]);
+    double* slot = lds + (size_t)(e - wblock / lanes_per_e) * (NV * RAPTOR_ID_SLOT);
+    const size_t rowbase = (size_t)b * L.m;
+    const bool lead = (c == 0) && (G != nullptr);
 
     int jd = -1;
     double w0 = 0.0, w1 = 0.0, w2 = 0.0;
     if (DERIV) column_direction(T, basis, wsum, i, c, jd, w0, w1, w2);
 
-    // ---- forward sweep (world frame) ----
-    SV s_[NV], f_[NV], df_[NV];
     M3 Rw;
 #pragma unroll
     for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -114,42 +139,70 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void id_kernel(const DevModel* __rest
     SV v = sv_zero();
     SV a = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};  // -a_grav
     SV dv = sv_zero(), da = sv_zero(), Delta = sv_zero();
-
+    double dtau[NV];
 #pragma unroll
+    for (int j = 0; j < NV; j++) dtau[j] = 0.0;
+
+#pragma unroll 1
     for (int l = 0; l < NV; l++) {
+        double q, qd, qdd;
+        traj_joint(T, basis, z, i, l, q, qd, qdd);
         const M3 A = mul(Rw, M->plR[l]);
         V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
         double sq, cq;
-        sincos(q[l], &sq, &cq);
+        sincos(q, &sq, &cq);
         M3 R;
         SV s;
-        joint_world(M->jtype[l], q[l], cq, sq, A, R, o, s);
+        joint_world(M->jtype[l], q, cq, sq, A, R, o, s);
 
-        const SV sqd = s * qd[l];
+        const SV sqd = s * qd;
         const SV vi = v + sqd;
-        const SV ai = a + s * qdd[l] + crm(v, sqd);
+        const SV ai = a + s * qdd + crm(v, sqd);
         Inertia I;
         I.mass = M->mass[l];
         I.c = o + mul(R, v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]));
         rotate_inertia(R, M->Ic[l], I);
         const SV h = apply(I, vi);
         const SV g = apply(I, ai);
-        f_[l] = g + crf(vi, h);
-        s_[l] = s;
+        const SV f = g + crf(vi, h);
+        double* sl = slot + l * RAPTOR_ID_SLOT;
+        lds_put(sl, s);
+        lds_put(sl + 6, f);
+        // InverseDynamics.cpp:115-121 (damping, friction); armature is inside pinocchio::rnea (>= 3)
+        sl[12] = M->armature[l] * qdd + M->damping[l] * qd + M->friction[l] * sign_eps(qd);
+
+        // JointLimits / VelocityLimits rows (JointLimits.cpp:32-45, VelocityLimits.cpp:32-44)
+        if (L.off_q >= 0) {
+            const size_t row = rowbase + L.off_q + (size_t)i * NV + l;
+            if (DERIV) JAC[row * V + c] = (l == jd) ? w0 : 0.0;
+            if (lead) G[row] = q;
+        }
+        if (L.off_qd >= 0) {
+            const size_t row = rowbase + L.off_qd + (size_t)i * NV + l;
+            if (DERIV) JAC[row * V + c] = (l == jd) ? w1 : 0.0;
+            if (lead) G[row] = qd;
+        }
 
         if (DERIV) {
             const bool isk = (l == jd);
             if (isk) Delta = s * w0;
             const SV ds = crm(Delta, s);  // zero up to and including the driven joint
             const double dqd = isk ? w1 : 0.0, dqdd = isk ? w2 : 0.0;
-            const SV dsqd = ds * qd[l] + s * dqd;
+            const SV dsqd = ds * qd + s * dqd;
             const SV dvi = dv + dsqd;
-            const SV dai = da + ds * qdd[l] + s * dqdd + crm(dv, sqd) + crm(v, dsqd);
+            const SV dai = da + ds * qdd + s * dqdd + crm(dv, sqd) + crm(v, dsqd);
             const SV dpv = dvi - crm(Delta, vi);  // derivative as seen in the moving body
             const SV dpa = dai - crm(Delta, ai);
-            df_[l] = crf(Delta, g) + apply(I, dpa) + crf(dvi, h) + crf(vi, crf(Delta, h) + apply(I, dpv));
+            const SV df = crf(Delta, g) + apply(I, dpa) + crf(dvi, h) + crf(vi, crf(Delta, h) + apply(I, dpv));
             dv = dvi;
             da = dai;
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                if (j <= l) {
+                    dtau[j] += dot(lds_sv(slot + j * RAPTOR_ID_SLOT), df);
+                    if (j == l && isk) dtau[j] += M->armature[l] * w2 + M->damping[l] * w1;
+                }
+            }
         }
         v = vi;
         a = ai;
@@ -158,40 +211,19 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void id_kernel(const DevModel* __rest
     }
 
     // ---- backward sweep: suffix sums of wrenches, no transforms needed in the world frame ----
-    const size_t rowbase = (size_t)b * L.m;
-    SV F = sv_zero(), dF = sv_zero();
+    SV F = sv_zero();
 #pragma unroll
     for (int l = NV - 1; l >= 0; l--) {
-        F = F + f_[l];
-        // InverseDynamics.cpp:115-121 (damping, friction) and armature inside pinocchio::rnea (>= 3)
-        const double tau = dot(s_[l], F) + M->armature[l] * qdd[l] + M->damping[l] * qd[l] + M->friction[l] * sign_eps(qd[l]);
+        const double* sl = slot + l * RAPTOR_ID_SLOT;
+        const SV s = lds_sv(sl);
+        F = F + lds_sv(sl + 6);
         const size_t row = rowbase + L.off_tau + (size_t)i * NV + l;
         if (DERIV) {
-            dF = dF + df_[l];
-            double dtau = dot(s_[l], dF);
-            if (l > jd) dtau += dot(crm(Delta, s_[l]), F);
-            if (l == jd) dtau += M->armature[l] * w2 + M->damping[l] * w1;
-            JAC[row * V + c] = dtau;
+            double d = dtau[l];
+            if (l > jd) d += dot(crm(Delta, s), F);
+            JAC[row * V + c] = d;
         }
-        if (c == 0 && G != nullptr) G[row] = tau;
-    }
-
-    // ---- JointLimits / VelocityLimits rows (JointLimits.cpp:32-45, VelocityLimits.cpp:32-44) ----
-    if (L.off_q >= 0) {
-#pragma unroll
-        for (int l = 0; l < NV; l++) {
-            const size_t row = rowbase + L.off_q + (size_t)i * NV + l;
-            if (DERIV) JAC[row * V + c] = (l == jd) ? w0 : 0.0;
-            if (c == 0 && G != nullptr) G[row] = q[l];
-        }
-    }
-    if (L.off_qd >= 0) {
-#pragma unroll
-        for (int l = 0; l < NV; l++) {
-            const size_t row = rowbase + L.off_qd + (size_t)i * NV + l;
-            if (DERIV) JAC[row * V + c] = (l == jd) ? w1 : 0.0;
-            if (c == 0 && G != nullptr) G[row] = qd[l];
-        }
+        if (lead) G[row] = dot(s, F) + sl[12];
     }
 }
 

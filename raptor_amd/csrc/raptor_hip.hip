@@ -103,6 +103,13 @@ struct raptor_problem {
     DevBuf<DevBox> d_boxes;
     // staging for the *_host entry points (grown on demand, reused)
     DevBuf<double> s_Z, s_G, s_J, s_a, s_b, s_c;
+    // optional per-kernel HIP-event timing (raptor_profile_begin / _end)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;   // 3 per evaluation: before K_id, between, after K_obs
+    size_t ev_used = 0;
+    ~raptor_problem() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
 };
 
 namespace {
@@ -247,12 +254,18 @@ void check_launchable(const raptor_problem& p, int B) {
 
 template <bool DERIV>
 void launch_id(raptor_problem& p, const DevLayout& L, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
-    const long long total = (long long)B * p.htraj.N * (DERIV ? L.n : 1);
+    const int lanes_per_e = DERIV ? L.n : 1;
+    const long long total = (long long)B * p.htraj.N * lanes_per_e;
     if (total == 0) return;
     if (!p.hmodel.serial_chain) throw unsupported_error("inverse dynamics kernel: only serial-chain models are built so far");
+    // one LDS slot per sample-eval touched by a block; the values-only kernel (one lane per e) uses 64-lane blocks
+    const int block = DERIV ? RAPTOR_BLOCK : 64;
+    const int slots = block / lanes_per_e + 2;
+    const size_t lds_bytes = (size_t)slots * p.hmodel.nv * RAPTOR_ID_SLOT * sizeof(double);
+    const unsigned grid = (unsigned)((total + block - 1) / block);
     switch (p.hmodel.nv) {
         case 7:
-            hipLaunchKernelGGL((id_kernel<7, DERIV>), dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p,
+            hipLaunchKernelGGL((id_kernel<7, DERIV>), dim3(grid), dim3(block), lds_bytes, st, p.d_model.p,
                                p.d_traj.p, p.d_basis.p, p.d_wsum.p, L, dZ, total, dG, dJ);
             break;
         default:
@@ -279,12 +292,18 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     check_launchable(p, B);
     if (B == 0) return;
     if (!(flags & RAPTOR_EVAL_G)) dG = nullptr;
-    if (jac) {
-        launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
-        if (p.kind == 1) launch_obs<true>(p, dZ, B, dG, dJ, st);
-    } else {
-        launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
-        if (p.kind == 1) launch_obs<false>(p, dZ, B, dG, nullptr, st);
+    const bool prof = p.profiling && p.ev_used + 3 <= p.ev.size();
+    if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used], st));
+    if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
+    else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
+    if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+    if (p.kind == 1) {
+        if (jac) launch_obs<true>(p, dZ, B, dG, dJ, st);
+        else launch_obs<false>(p, dZ, B, dG, nullptr, st);
+    }
+    if (prof) {
+        HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
+        p.ev_used += 3;
     }
 }
 
@@ -546,6 +565,40 @@ int raptor_inverse_dynamics_eval_host(raptor_problem* p, const double* Z, int B,
     HIP_CHECK(hipDeviceSynchronize());
     if (tau) HIP_CHECK(hipMemcpy(tau, p->s_G.p, (size_t)B * rows * sizeof(double), hipMemcpyDeviceToHost));
     if (ptau_pz) HIP_CHECK(hipMemcpy(ptau_pz, p->s_J.p, (size_t)B * rows * n * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_profile_begin(raptor_problem* p, int max_evaluations) {
+    API_TRY
+    if (!p || max_evaluations < 0) throw std::invalid_argument("bad argument");
+    while (p->ev.size() < (size_t)max_evaluations * 3) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    p->ev_used = 0;
+    p->profiling = true;
+    API_CATCH
+}
+
+int raptor_profile_end(raptor_problem* p, int* evaluations, double* id_ms_avg, double* obs_ms_avg) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    p->profiling = false;
+    const size_t n = p->ev_used / 3;
+    double a = 0, b = 0;
+    for (size_t i = 0; i < n; i++) {
+        HIP_CHECK(hipEventSynchronize(p->ev[3 * i + 2]));
+        float t0 = 0, t1 = 0;
+        HIP_CHECK(hipEventElapsedTime(&t0, p->ev[3 * i], p->ev[3 * i + 1]));
+        HIP_CHECK(hipEventElapsedTime(&t1, p->ev[3 * i + 1], p->ev[3 * i + 2]));
+        a += t0;
+        b += t1;
+    }
+    if (evaluations) *evaluations = (int)n;
+    if (id_ms_avg) *id_ms_avg = n ? a / n : 0.0;
+    if (obs_ms_avg) *obs_ms_avg = n ? b / n : 0.0;
+    p->ev_used = 0;
     API_CATCH
 }
 
