@@ -9,7 +9,7 @@ batch of B = 4096 decision vectors x N = 128 time samples = 524 288 sample-evals
 resident in HBM (BASELINE.json configs[1]).  With N GPUs every rank evaluates its own batch of 4096
 (multi-start problems are independent: weak scaling, no data-path collective).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the inverse-dynamics kernel K_id),
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused Kinova evaluation kernel),
 timed live with HIP events recorded on the evaluation stream inside the timed region;
 `cpu_baseline` is the CPU oracle (a restatement of the reference: kind "port") timed on one host core
 over a bounded sample of the same batch.
@@ -32,12 +32,11 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
 N_SAMPLES = 128
 BATCH = 4096
 # algorithmic bytes per sample-eval = rows written once x (7 Jacobian columns + 1 value) x 8 B
-ROWS_ID = 21    # JointLimits 7 + VelocityLimits 7 + TorqueLimits 7 rows per sample (K_id)
-ROWS_OBS = 17   # one row per collision sphere (K_obs)
-BYTES_ID = ROWS_ID * 8 * 8
-BYTES_OBS = ROWS_OBS * 8 * 8
-# algorithmic flops per sample-eval for K_id: RNEA 550*nv + analytic derivatives ~7e3 + contraction 2058
-FLOPS_ID = 550 * 7 + 7000 + 2058
+ROWS = 21 + 17  # JointLimits 7 + VelocityLimits 7 + TorqueLimits 7 rows + one row per collision sphere, per sample
+BYTES_ID = ROWS * 8 * 8   # 2432 B per sample-eval, the whole evaluation is one fused kernel
+# algorithmic flops per sample-eval: RNEA 550*nv + analytic derivatives ~7e3 + contraction 2058
+# + sphere FK / box distances ~25e3
+FLOPS_ID = 550 * 7 + 7000 + 2058 + 25000
 
 
 def main() -> None:
@@ -136,19 +135,19 @@ def main() -> None:
             },
             "eval_jac_g_latency_ms_batch": ms_per_step,
             "roofline": {
-                "kernel": "id_kernel<7,true> (trajectory + RNEA + d tau/dz + limit rows)",
+                "kernel": "kinova_fused_kernel<true> (trajectory + RNEA + d tau/dz + limit rows + sphere/box rows)",
                 "bound": "hbm",
                 "achieved": sample_evals * BYTES_ID / id_s / 1e9 if id_s > 0 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (sample_evals * BYTES_ID / id_s / 1e9) / HBM_PEAK_GBS if id_s > 0 else None,
-                "traffic": None,
+                "traffic": pmc_traffic(sample_evals * BYTES_ID),
                 "kernel_ms": id_ms,
                 "launches_timed": n_prof,
                 "algorithmic_bytes_per_launch": sample_evals * BYTES_ID,
             },
             "roofline_fp64": {
-                "kernel": "id_kernel<7,true>",
+                "kernel": "kinova_fused_kernel<true>",
                 "bound": "fp64-valu",
                 "achieved": sample_evals * FLOPS_ID / id_s / 1e12 if id_s > 0 else None,
                 "peak": FP64_PEAK_TFLOPS,
@@ -156,19 +155,24 @@ def main() -> None:
                 "frac": (sample_evals * FLOPS_ID / id_s / 1e12) / FP64_PEAK_TFLOPS if id_s > 0 else None,
                 "algorithmic_flops_per_sample_eval": FLOPS_ID,
             },
-            "other_kernels": {
-                "kinova_obs_kernel<7,true>": {
-                    "kernel_ms": obs_ms,
-                    "achieved_GBs": sample_evals * BYTES_OBS / (obs_ms * 1e-3) / 1e9 if obs_ms > 0 else None,
-                }
-            },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, boxes, Z[:64].cpu().numpy(), args.cpu_seconds, G, J, prob)
+            out["cpu_baseline"] = cpu_baseline(model, boxes, Z.cpu().numpy(), args.cpu_seconds, G, J, prob)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(algorithmic_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
+    collected with this same command in separate WRITE_SIZE / FETCH_SIZE runs); None when no such file is present."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        k = d["kinova_fused_kernel<true>"]
+        return k["WRITE_SIZE_bytes"] + k["FETCH_SIZE_bytes"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(model, boxes, Zs, budget_s, G, J, prob):

@@ -169,9 +169,10 @@ int raptor_capsule_distance_batch_host(const double* P, const double* dP, const 
 /*
  * Per-kernel timing with HIP events recorded on the evaluation stream, for measurement harnesses
  * (the reference keeps per-callback wall-clock counters instead: Optimization/src/Optimizer.cpp:717-754).
- * Between _begin and _end every raptor_eval_batch records three events (before the inverse-dynamics
- * kernel, between the kernels, after the obstacle kernel), up to max_evaluations calls; _end waits for
- * them and returns the average duration of each kernel in milliseconds.
+ * Between _begin and _end every raptor_eval_batch records events around its kernel launches, up to
+ * max_evaluations calls; _end waits for them and returns the average duration in milliseconds of the
+ * evaluation kernel (id_ms_avg) and of any follow-up kernel (obs_ms_avg; 0 since the Kinova path is one
+ * fused kernel).
  */
 int raptor_profile_begin(raptor_problem* problem, int max_evaluations);
 int raptor_profile_end(raptor_problem* problem, int* evaluations, double* id_ms_avg, double* obs_ms_avg);

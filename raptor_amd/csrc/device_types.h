@@ -43,6 +43,7 @@ struct DevSpheres {
     int num_spheres;
     int num_obstacles;
     int joint_id[RAPTOR_MAX_SPHERES];  // Pinocchio joint id (1-based) the sphere is attached to
+    int ro_slot[RAPTOR_MAX_NV];        // link -> slot of its world pose in the kernel's LDS exchange area (-1: no sphere)
     double offset[RAPTOR_MAX_SPHERES][3];
     double radius[RAPTOR_MAX_SPHERES];
 };

@@ -3,8 +3,7 @@
 //   K_id   (id_kernel)          one lane per (decision vector b, time sample i, column c of z):
 //                               trajectory -> world-frame RNEA -> directional derivative along column c
 //                               -> TorqueLimits rows (+ JointLimits / VelocityLimits rows).
-//   K_obs  (kinova_obs_kernel)  one lane per (b, i, collision sphere): chain FK -> sphere centre and
-//                               its Jacobian -> min signed distance over the boxes -> gradient row.
+//   K_kinova (kinova_kernel.h)  the whole Kinova evaluation fused, 8 lanes per sample-eval (analytic derivatives).
 //   K_traj (traj_kernel)        q, q_d, q_dd only (component view for the parity tests).
 //
 // Why a column per lane.  d(tau)/dz is needed for every column of z.  For the trajectories on this path a
@@ -224,171 +223,6 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void id_kernel(const DevModel* __r
             JAC[row * V + c] = d;
         }
         if (lead) G[row] = dot(s, F) + sl[12];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K_obs : KinovaCustomizedConstraints::compute (KinovaCustomizedConstraints.cpp:73-158) with
-//         BoxCollisionAvoidance::computeDistance (BoxCollisionAvoidance.cpp:92-204, 290-373)
-// ---------------------------------------------------------------------------------------------
-template <int NV, bool DERIV>
-__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_obs_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
-                                                                   const double* __restrict__ basis,
-                                                                   const double* __restrict__ wsum,
-                                                                   const DevSpheres* __restrict__ S,
-                                                                   const DevBox* __restrict__ boxes, const DevLayout L,
-                                                                   const double* __restrict__ Z, const long long total,
-                                                                   double* __restrict__ G, double* __restrict__ JAC) {
-    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
-    if (w >= total) return;
-    const int V = L.n;
-    const int N = T->N;
-    const int ns = S->num_spheres;
-    const int sp = (int)(w % ns);
-    const long long e = w / ns;
-    const int i = (int)(e % N);
-    const long long b = e / N;
-    const double* z = Z + b * V;
-    const size_t row = (size_t)b * L.m + L.off_obs + (size_t)i * ns + sp;
-
-    const int O = S->num_obstacles;
-    if (O == 0) {  // KinovaCustomizedConstraints.cpp:80-82: g and pg_pz keep their zero initialisation
-        if (G != nullptr) G[row] = 0.0;
-        if (DERIV)
-            for (int c = 0; c < V; c++) JAC[row * V + c] = 0.0;
-        return;
-    }
-
-    const int jid = S->joint_id[sp];  // chain = joints 0 .. jid-1
-    // forward kinematics along the chain, world frame
-    M3 Rw;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    V3 ow = v3(0, 0, 0);
-    V3 ax_[NV], o_[NV];
-    bool rev_[NV];
-#pragma unroll
-    for (int l = 0; l < NV; l++) {
-        if (l < jid) {
-            double q, qd, qdd;
-            traj_joint(T, basis, z, i, l, q, qd, qdd);
-            const M3 A = mul(Rw, M->plR[l]);
-            V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
-            double sq, cq;
-            sincos(q, &sq, &cq);
-            M3 R;
-            SV s;
-            joint_world(M->jtype[l], q, cq, sq, A, R, o, s);
-            const int aj = M->jtype[l] < 0 ? -M->jtype[l] : M->jtype[l];
-            rev_[l] = aj <= 3;
-            ax_[l] = rev_[l] ? s.a : s.l;
-            o_[l] = o;
-            Rw = R;
-            ow = o;
-        } else {
-            rev_[l] = false;
-            ax_[l] = v3(0, 0, 0);
-            o_[l] = v3(0, 0, 0);
-        }
-    }
-    const V3 point = ow + mul(Rw, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
-
-    // min over obstacles; strict '<' keeps the first minimum (BoxCollisionAvoidance.cpp:305-308)
-    double minDist = 1e19;
-    int minIdx = 0;
-    for (int ob = 0; ob < O; ob++) {
-        const DevBox* __restrict__ bx = boxes + ob;
-        M3 R;
-#pragma unroll
-        for (int k = 0; k < 9; k++) R.m[k] = bx->R[k];
-        const V3 ctr = v3(bx->center[0], bx->center[1], bx->center[2]);
-        const V3 lp = mulT(R, point - ctr);
-        const double lpv[3] = {lp.x, lp.y, lp.z};
-        double lc[3], dface[3][2];
-        double isInside = -1.0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double hs = bx->size[k] / 2.0;
-            dface[k][0] = lpv[k] + hs;
-            dface[k][1] = hs - lpv[k];
-            lc[k] = fmax(-hs, fmin(lpv[k], hs));
-            if (lc[k] != lpv[k]) isInside = 1.0;
-        }
-        if (isInside == -1.0) {  // point inside the box: snap to the nearest face (:112-131)
-            double md = 1e19;
-            int face = 0, dir = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
-                if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (k == face) lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0;
-        }
-        const V3 closest = mul(R, v3(lc[0], lc[1], lc[2])) + ctr;
-        const V3 diff = point - closest;
-        const double d2 = dot(diff, diff);
-        const double dist = (d2 > 1e-12) ? isInside * sqrt(d2) : 0.0;  // SQUARE_ROOT_THRESHOLD
-        if (dist < minDist) {
-            minDist = dist;
-            minIdx = ob;
-        }
-    }
-    if (G != nullptr) G[row] = minDist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
-
-    if (DERIV) {
-        // recompute the closest-point difference for the arg-min box with derivative bookkeeping (:139-204, :359-372)
-        const DevBox* __restrict__ bx = boxes + minIdx;
-        M3 R;
-#pragma unroll
-        for (int k = 0; k < 9; k++) R.m[k] = bx->R[k];
-        const V3 ctr = v3(bx->center[0], bx->center[1], bx->center[2]);
-        const V3 lp = mulT(R, point - ctr);
-        const double lpv[3] = {lp.x, lp.y, lp.z};
-        double lc[3], dface[3][2], keep[3];
-        double isInside = -1.0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double hs = bx->size[k] / 2.0;
-            dface[k][0] = lpv[k] + hs;
-            dface[k][1] = hs - lpv[k];
-            if (lpv[k] < -hs) { lc[k] = -hs; isInside = 1.0; keep[k] = 0.0; }
-            else if (lpv[k] > hs) { lc[k] = hs; isInside = 1.0; keep[k] = 0.0; }
-            else { lc[k] = lpv[k]; keep[k] = 1.0; }
-        }
-        if (isInside == -1.0) {
-            double md = 1e19;
-            int face = 0, dir = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
-                if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (k == face) { lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0; keep[k] = 0.0; }
-        }
-        const V3 closest = mul(R, v3(lc[0], lc[1], lc[2])) + ctr;
-        const V3 diff = point - closest;
-        const double d2 = dot(diff, diff);
-        const bool ok = d2 > 1e-12;
-        const double scale = ok ? isInside / sqrt(d2) : 0.0;
-        // pg_pz row: column c = d(centre)/dq_c * pq_pz(c,c); ArmourBezier: pq_pz = w0 * I
-        const double w0 = wsum[i * 3];
-#pragma unroll
-        for (int l = 0; l < NV; l++) {
-            double gcol = 0.0;
-            if (l < jid) {
-                // ForwardKinematics.cpp:330-341: dTdq[l].p
-                const V3 pc = (rev_[l] ? cross(ax_[l], point - o_[l]) : ax_[l]) * w0;
-                V3 pl = mulT(R, pc);
-                pl = v3(pl.x * keep[0], pl.y * keep[1], pl.z * keep[2]);
-                const V3 pdiff = pc - mul(R, pl);
-                gcol = scale * dot(diff, pdiff);
-            }
-            JAC[row * V + l] = gcol;
-        }
     }
 }
 

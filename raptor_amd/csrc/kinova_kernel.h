@@ -1,0 +1,361 @@
+// K_kinova : the whole Kinova constraint evaluation for one sample-eval in ONE 8-lane group
+// (eval_g / eval_jac_g of KinovaOptimizer: joint, velocity, torque limits + sphere/box obstacle rows).
+//
+// MI355X design (not a translation of the reference's per-class loops):
+//   * a 256-lane workgroup owns 32 sample-evals; each sample-eval (b, i) is worked on by 8 adjacent
+//     lanes of one wavefront, so the lanes of a group exchange data through LDS / wave shuffles
+//     without any workgroup barrier;
+//   * lane g owns joint g:  trajectory value + sincos (phase 0), its link's world-frame kinematics
+//     (phase A: the link recursion runs with a per-lane trip count, lane g stops at link g),
+//     its link's spatial inertia, momentum, wrench and Coriolis term (phase B);
+//   * composite (subtree) quantities are an 8-lane suffix scan with wave shuffles (phase C);
+//   * d(tau)/dz comes from the analytic world-frame identities below, NOT from nv-column forward
+//     mode: with s_k the joint axis, sd_k = v_k x s_k, psi_k = a_k x s_k + v_k x sd_k, composite
+//     inertia I^C_j, momentum H^C_j, wrench F_j and Q^C_j = sum_{l in subtree(j)} (v_l x*) I_l + transpose,
+//         column k, row j >= k :  IS_j . gamma_k + BtS_j . beta_k        (IS = I^C s, BtS = Q^C s - s x* H^C)
+//         column k, row j <  k :  s_j . (w2 IS_k + w1 (2 I^C sd + Q^C s + s x* H^C) + w0 (I^C psi + Q^C sd + sd x* H^C + s x* F))_k
+//         gamma_k = w2 s + 2 w1 sd + w0 psi,  beta_k = w1 s + w0 sd,  (w0,w1,w2) = (pq_pz, pq_d_pz, pq_dd_pz)(k,k)
+//     (derivation and numpy check: scripts/proto_world_derivs.py, scripts/proto_reduced_form.py;
+//      this equals InverseDynamics.cpp:137-139 prnea_pq*pq_pz + prnea_pv*pv_pz + prnea_pa*pa_pz);
+//   * the 17 (+3) collision spheres are dealt round-robin to the 8 lanes; the sphere Jacobian needs no
+//     extra kinematics because d(centre)/dq_c . diff = s_c . [centre x diff ; diff];
+//   * every Jacobian row is staged in LDS and leaves the workgroup as 16-byte-per-lane contiguous
+//     stores (the per-e rows of one constraint block are contiguous in Optimizer order).
+#ifndef RAPTOR_KINOVA_KERNEL_H
+#define RAPTOR_KINOVA_KERNEL_H
+
+#include "kernels.h"
+
+#define KG 8       // lanes per sample-eval
+#define K_EPB 32   // sample-evals per 256-lane workgroup
+// LDS layout per sample-eval, in doubles
+#define KL_S 0        // s_j            7 x 6
+#define KL_RO 42      // R, o of up to 4 sphere links   4 x 12
+#define KL_OUT 90     // ptau_pz(i)     7 x 7
+#define KL_X 139      // phase 0 exchange (7 x 5), then IS/BtS (7 x 12) at +35; later sphere rows (ns x 7 <= 140)
+#define KL_STRIDE 282  // >= 279; 564 dwords: the 8 groups of a wave fall on disjoint LDS banks
+
+RD void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inertia about the world origin: mass, first moment hv = m c, rotational inertia IO (symmetric)
+struct InertiaO {
+    double m;
+    V3 hv;
+    double xx, xy, xz, yy, yz, zz;
+};
+RD V3 symmul(double xx, double xy, double xz, double yy, double yz, double zz, V3 a) {
+    return V3{xx * a.x + xy * a.y + xz * a.z, xy * a.x + yy * a.y + yz * a.z, xz * a.x + yz * a.y + zz * a.z};
+}
+RD SV applyO(const InertiaO& I, SV x) {
+    return SV{symmul(I.xx, I.xy, I.xz, I.yy, I.yz, I.zz, x.a) + cross(I.hv, x.l), x.l * I.m + cross(x.a, I.hv)};
+}
+// Q x,  Q = [[QTL, [t]x], [-[t]x, 0]]
+RD SV applyQ(const double* Q, V3 t, SV x) {
+    return SV{symmul(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], x.a) + cross(t, x.l), cross(x.a, t)};
+}
+RD double shfl_down8(double x, int d) { return __shfl_down(x, d, KG); }
+
+template <bool DERIV>
+__global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
+    const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
+    const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes,
+    const DevLayout L, const double* __restrict__ Z, const long long E, double* __restrict__ G,
+    double* __restrict__ JAC) {
+    extern __shared__ double lds[];
+    constexpr int NV = 7;
+    const int tid = threadIdx.x;
+    const int g = tid & (KG - 1);
+    const int eg = tid >> 3;
+    const long long e0 = (long long)blockIdx.x * K_EPB;
+    const long long e = e0 + eg;
+    const int N = T->N;
+    const int ns = S->num_spheres;
+    double* sl = lds + eg * KL_STRIDE;
+
+    if (e < E) {
+        const int i = (int)(e % N);
+        const long long b = e / N;
+        const double* z = Z + b * NV;
+        const size_t rowbase = (size_t)b * L.m;
+        const bool own = g < NV;  // lane 7 owns no joint
+        const int gl = own ? g : NV - 1;
+
+        // ---- phase 0: joint g's trajectory value and sincos ----
+        double q, qd, qdd, sq, cq;
+        traj_joint(T, basis, z, i, gl, q, qd, qdd);
+        sincos(q, &sq, &cq);
+        if (own) {
+            double* x = sl + KL_X + g * 5;
+            x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
+            if (G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
+                G[rowbase + L.off_q + (size_t)i * NV + g] = q;
+                G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;
+            }
+        }
+        wave_sync();
+
+        // ---- phase A: world-frame kinematics down to link gl (per-lane trip count) ----
+        M3 Rw;
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        V3 ow = v3(0, 0, 0);
+        SV v = sv_zero(), vprev = sv_zero();
+        SV a = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
+        SV s = sv_zero();
+#pragma unroll 1
+        for (int l = 0; l <= gl; l++) {
+            const double* x = sl + KL_X + l * 5;
+            const double lqd = x[0], lqdd = x[1], lcq = x[2], lsq = x[3], lq = x[4];
+            const M3 A = mul(Rw, M->plR[l]);
+            V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+            M3 R;
+            joint_world(M->jtype[l], lq, lcq, lsq, A, R, o, s);
+            const SV sqd = s * lqd;
+            vprev = v;
+            a = a + s * lqdd + crm(v, sqd);
+            v = v + sqd;
+            Rw = R;
+            ow = o;
+        }
+        const SV sd = crm(vprev, s);  // = v x s
+        if (own) {
+            lds_put(sl + KL_S + g * 6, s);
+            const int slot = S->ro_slot[g];
+            if (slot >= 0) {
+                double* ro = sl + KL_RO + slot * 12;
+#pragma unroll
+                for (int k = 0; k < 9; k++) ro[k] = Rw.m[k];
+                ro[9] = ow.x; ro[10] = ow.y; ro[11] = ow.z;
+            }
+        }
+
+        // ---- phase B: link g's inertia, momentum, wrench, Coriolis term (world frame, about the origin) ----
+        InertiaO I;
+        SV h, f;
+        double Qt[6];
+        {
+            Inertia Ic;
+            const V3 c = ow + mul(Rw, v3(M->lever[gl][0], M->lever[gl][1], M->lever[gl][2]));
+            rotate_inertia(Rw, M->Ic[gl], Ic);
+            const double m = own ? M->mass[gl] : 0.0;
+            const double keep = own ? 1.0 : 0.0;
+            I.m = m;
+            I.hv = c * m;
+            const double cc = dot(c, c);
+            I.xx = keep * Ic.xx + m * (cc - c.x * c.x);
+            I.yy = keep * Ic.yy + m * (cc - c.y * c.y);
+            I.zz = keep * Ic.zz + m * (cc - c.z * c.z);
+            I.xy = keep * Ic.xy - m * c.x * c.y;
+            I.xz = keep * Ic.xz - m * c.x * c.z;
+            I.yz = keep * Ic.yz - m * c.y * c.z;
+            h = applyO(I, v);
+            f = applyO(I, a) + crf(v, h);
+            if (DERIV) {
+                // QTL = W + W^T - (hv u^T + u hv^T) + 2 (u.hv) 1,   W = [w]x IO
+                const V3 w = v.a, u = v.l;
+                const V3 c0 = cross(w, v3(I.xx, I.xy, I.xz));  // W[:,0]
+                const V3 c1 = cross(w, v3(I.xy, I.yy, I.yz));
+                const V3 c2 = cross(w, v3(I.xz, I.yz, I.zz));
+                const double uh = 2.0 * dot(u, I.hv);
+                Qt[0] = 2.0 * c0.x - 2.0 * I.hv.x * u.x + uh;
+                Qt[1] = c1.x + c0.y - (I.hv.x * u.y + u.x * I.hv.y);
+                Qt[2] = c2.x + c0.z - (I.hv.x * u.z + u.x * I.hv.z);
+                Qt[3] = 2.0 * c1.y - 2.0 * I.hv.y * u.y + uh;
+                Qt[4] = c2.y + c1.z - (I.hv.y * u.z + u.y * I.hv.z);
+                Qt[5] = 2.0 * c2.z - 2.0 * I.hv.z * u.z + uh;
+            }
+        }
+
+        // ---- phase C: composites = suffix sums over the chain (8-lane scan, lane 7 contributes zero) ----
+        SV F = f, H = h;
+#pragma unroll
+        for (int d = 1; d < KG; d <<= 1) {
+            const bool take = (g + d) < KG;
+#define SCAN(x) { const double y_ = shfl_down8(x, d); if (take) x += y_; }
+            SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
+            if (DERIV) {
+                SCAN(H.a.x) SCAN(H.a.y) SCAN(H.a.z) SCAN(H.l.x) SCAN(H.l.y) SCAN(H.l.z)
+                SCAN(I.m) SCAN(I.hv.x) SCAN(I.hv.y) SCAN(I.hv.z)
+                SCAN(I.xx) SCAN(I.xy) SCAN(I.xz) SCAN(I.yy) SCAN(I.yz) SCAN(I.zz)
+                SCAN(Qt[0]) SCAN(Qt[1]) SCAN(Qt[2]) SCAN(Qt[3]) SCAN(Qt[4]) SCAN(Qt[5])
+            }
+#undef SCAN
+        }
+
+        // ---- phase D: joint torque, and the per-joint 6-vectors of the analytic derivative ----
+        if (own && G != nullptr) {
+            // InverseDynamics.cpp:115-121 (damping, friction); armature inside pinocchio::rnea (>= 3)
+            G[rowbase + L.off_tau + (size_t)i * NV + g] =
+                dot(s, F) + M->armature[g] * qdd + M->damping[g] * qd + M->friction[g] * sign_eps(qd);
+        }
+        double w0 = 0.0;
+        if (DERIV) {
+            w0 = wsum[i * 3];
+            const double w1 = wsum[i * 3 + 1], w2 = wsum[i * 3 + 2];
+            const SV psi = crm(a, s) + crm(v, sd);
+            const SV IS = applyO(I, s);
+            const SV IdS = applyO(I, sd);
+            const SV Ipsi = applyO(I, psi);
+            const SV QS = applyQ(Qt, H.l, s);
+            const SV QdS = applyQ(Qt, H.l, sd);
+            const SV HS = crf(s, H);
+            const SV HdS = crf(sd, H);
+            const SV cF = crf(s, F);
+            const SV BtS = QS - HS;
+            const SV cv = IdS * 2.0 + QS + HS;
+            const SV cq_ = Ipsi + QdS + HdS + cF;
+            const SV p = IS * w2 + cv * w1 + cq_ * w0;
+            const SV gam = s * w2 + sd * (2.0 * w1) + psi * w0;
+            const SV bet = s * w1 + sd * w0;
+            if (own) {
+                lds_put(sl + KL_X + 35 + g * 12, IS);
+                lds_put(sl + KL_X + 35 + g * 12 + 6, BtS);
+            }
+            wave_sync();
+            // ---- phase E: lane g = column g of ptau_pz(i) ----
+            if (own) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    double d;
+                    if (j < g) {
+                        d = dot(lds_sv(sl + KL_S + j * 6), p);
+                    } else {
+                        d = dot(lds_sv(sl + KL_X + 35 + j * 12), gam) + dot(lds_sv(sl + KL_X + 35 + j * 12 + 6), bet);
+                        if (j == g) d += M->armature[g] * w2 + M->damping[g] * w1;
+                    }
+                    sl[KL_OUT + j * NV + g] = d;
+                }
+            }
+        }
+        wave_sync();  // the exchange area is reused for the sphere rows below
+
+        // ---- spheres: KinovaCustomizedConstraints.cpp:88-157, BoxCollisionAvoidance.cpp:92-137, 290-373 ----
+        const int O = S->num_obstacles;
+        for (int sp = g; sp < ns; sp += KG) {
+            const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
+            if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
+                if (G != nullptr) G[row] = 0.0;
+                if (DERIV)
+#pragma unroll
+                    for (int c = 0; c < NV; c++) sl[KL_X + sp * NV + c] = 0.0;
+                continue;
+            }
+            const int jid = S->joint_id[sp];
+            const double* ro = sl + KL_RO + S->ro_slot[jid - 1] * 12;
+            M3 R;
+#pragma unroll
+            for (int k = 0; k < 9; k++) R.m[k] = ro[k];
+            const V3 point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+            double minDist = 1e19, bd2 = 0.0, bsign = 1.0;
+            V3 bdl = v3(0, 0, 0);
+            int minIdx = 0;
+            for (int ob = 0; ob < O; ob++) {
+                const DevBox* __restrict__ bx = boxes + ob;
+                M3 Rb;
+#pragma unroll
+                for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+                const V3 lp = mulT(Rb, point - v3(bx->center[0], bx->center[1], bx->center[2]));
+                const double lpv[3] = {lp.x, lp.y, lp.z};
+                double lc[3], dface[3][2];
+                double isInside = -1.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double hs = bx->size[k] / 2.0;
+                    dface[k][0] = lpv[k] + hs;
+                    dface[k][1] = hs - lpv[k];
+                    lc[k] = fmax(-hs, fmin(lpv[k], hs));
+                    if (lc[k] != lpv[k]) isInside = 1.0;
+                }
+                if (isInside == -1.0) {  // inside: snap to the nearest face, first minimum wins (:112-131)
+                    double md = 1e19;
+                    int face = 0, dir = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
+                        if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        if (k == face) lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0;
+                }
+                // |point - closest| is rotation invariant: measure it in the box frame
+                const V3 dl = v3(lpv[0] - lc[0], lpv[1] - lc[1], lpv[2] - lc[2]);
+                const double d2 = dot(dl, dl);
+                const double dist = (d2 > 1e-12) ? isInside * sqrt(d2) : 0.0;  // SQUARE_ROOT_THRESHOLD
+                if (dist < minDist) {  // strict: first minimum wins (:305-308)
+                    minDist = dist;
+                    minIdx = ob;
+                    bd2 = d2;
+                    bsign = isInside;
+                    bdl = dl;
+                }
+            }
+            if (G != nullptr) G[row] = minDist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
+            if (DERIV) {
+                // gradient of the arg-min box (:359-372).  The clamped-axis mask of the reference drops out:
+                // diff has no component along unclamped axes, so d dist/dz_c = sign * diff . dp/dz_c / |diff|
+                // and diff . (w x (p - o) ) = s_c . [p x diff ; diff].
+                const DevBox* bx = boxes + minIdx;
+                M3 Rb;
+#pragma unroll
+                for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+                const V3 dw = mul(Rb, bdl);
+                const double scale = (bd2 > 1e-12) ? bsign * w0 / sqrt(bd2) : 0.0;
+                const SV Wr = SV{cross(point, dw), dw};
+#pragma unroll
+                for (int c = 0; c < NV; c++) {
+                    const double d = (c < jid) ? scale * dot(lds_sv(sl + KL_S + c * 6), Wr) : 0.0;
+                    sl[KL_X + sp * NV + c] = d;
+                }
+            }
+        }
+    }
+
+    if (!DERIV) return;
+    __syncthreads();
+
+    // ---- copy-out: contiguous runs per constraint block, 16 bytes per lane ----
+    const long long eend = (e0 + K_EPB < E) ? e0 + K_EPB : E;
+    long long ea = e0;
+    while (ea < eend) {  // one pass per decision vector touched by this workgroup
+        const long long b = ea / N;
+        const int ia = (int)(ea - b * N);
+        const long long eb = ((b + 1) * N < eend) ? (b + 1) * N : eend;
+        const int cnt = (int)(eb - ea);   // sample-evals in this run
+        const int el0 = (int)(ea - e0);   // first local slot
+        const size_t rowbase = (size_t)b * L.m;
+#pragma unroll 1
+        for (int region = 0; region < 4; region++) {
+            const int per_e = (region == 3) ? ns * NV : NV * NV;
+            const int off = (region == 0) ? L.off_q : (region == 1) ? L.off_qd : (region == 2) ? L.off_tau : L.off_obs;
+            const int rows_per_e = (region == 3) ? ns : NV;
+            double* dst = JAC + (rowbase + off + (size_t)ia * rows_per_e) * NV;
+            const int len = cnt * per_e;
+            const int lds_off = (region == 3) ? KL_X : KL_OUT;
+            auto value = [&](int t) -> double {
+                const int el = t / per_e;
+                const int r = t - el * per_e;
+                if (region < 2) {  // pq_pz / pq_d_pz are w * identity (ArmourBezierCurves.cpp:147-151)
+                    return (r % (NV + 1) == 0) ? wsum[(ia + el) * 3 + region] : 0.0;
+                }
+                return lds[(el0 + el) * KL_STRIDE + lds_off + r];
+            };
+            const int head = (int)(((size_t)dst >> 3) & 1);  // 16-byte alignment of the run
+            if (head && tid == 0 && len > 0) dst[0] = value(0);
+            const int pairs = (len - head) >> 1;
+            double2* dst2 = reinterpret_cast<double2*>(dst + head);
+            for (int pidx = tid; pidx < pairs; pidx += RAPTOR_BLOCK) {
+                const int t = head + 2 * pidx;
+                dst2[pidx] = make_double2(value(t), value(t + 1));
+            }
+            if (((len - head) & 1) && tid == RAPTOR_BLOCK - 1) dst[len - 1] = value(len - 1);
+        }
+        ea = eb;
+    }
+}
+
+#endif

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -13,6 +14,7 @@
 
 #include "kernels.h"
 #include "capsule_kernel.h"
+#include "kinova_kernel.h"
 
 namespace {
 
@@ -105,7 +107,7 @@ struct raptor_problem {
     DevBuf<double> s_Z, s_G, s_J, s_a, s_b, s_c;
     // optional per-kernel HIP-event timing (raptor_profile_begin / _end)
     bool profiling = false;
-    std::vector<hipEvent_t> ev;   // 3 per evaluation: before K_id, between, after K_obs
+    std::vector<hipEvent_t> ev;   // 3 per evaluation: before / after the evaluation kernel (third: reserved)
     size_t ev_used = 0;
     ~raptor_problem() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
@@ -275,11 +277,19 @@ void launch_id(raptor_problem& p, const DevLayout& L, const double* dZ, int B, d
 }
 
 template <bool DERIV>
-void launch_obs(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
-    const long long total = (long long)B * p.htraj.N * p.hspheres.num_spheres;
-    if (total == 0) return;
-    hipLaunchKernelGGL((kinova_obs_kernel<7, DERIV>), dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p,
-                       p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, total, dG, dJ);
+void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
+    const long long E = (long long)B * p.htraj.N;
+    if (E == 0) return;
+    const size_t lds_bytes = (size_t)K_EPB * KL_STRIDE * sizeof(double);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[DERIV]) {  // > 64 KiB of dynamic LDS needs the opt-in
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_fused_kernel<DERIV>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set[DERIV] = true;
+    }
+    const unsigned grid = (unsigned)((E + K_EPB - 1) / K_EPB);
+    hipLaunchKernelGGL((kinova_fused_kernel<DERIV>), dim3(grid), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_model.p,
+                       p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -294,13 +304,14 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     if (!(flags & RAPTOR_EVAL_G)) dG = nullptr;
     const bool prof = p.profiling && p.ev_used + 3 <= p.ev.size();
     if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used], st));
-    if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
-    else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
-    if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
-    if (p.kind == 1) {
-        if (jac) launch_obs<true>(p, dZ, B, dG, dJ, st);
-        else launch_obs<false>(p, dZ, B, dG, nullptr, st);
+    if (p.kind == 1) {  // Kinova: one fused kernel
+        if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
+        else launch_kinova<false>(p, dZ, B, dG, nullptr, st);
+    } else {
+        if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
+        else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
     }
+    if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
     if (prof) {
         HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
         p.ev_used += 3;
@@ -395,6 +406,15 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
         }
     }
     S.num_obstacles = d->num_obstacles;
+    {   // links that carry spheres publish their world pose to the 8-lane group (kinova_kernel.h, KL_RO)
+        for (int l = 0; l < RAPTOR_MAX_NV; l++) S.ro_slot[l] = -1;
+        int nslots = 0;
+        for (int s = 0; s < S.num_spheres; s++) {
+            const int l = S.joint_id[s] - 1;
+            if (S.ro_slot[l] < 0) S.ro_slot[l] = nslots++;
+        }
+        if (nslots > 4 || S.num_spheres > 20) throw unsupported_error("Kinova kernel: at most 4 sphere-carrying links / 20 spheres");
+    }
 
     // boxes: R = Rz(yaw) Ry(pitch) Rx(roll)  (BoxCollisionAvoidance.cpp:59-61)
     std::vector<DevBox> boxes(std::max(1, d->num_obstacles));

@@ -88,7 +88,7 @@ def test_kinova_eval_g_and_jac(oracle, hip, kinova, env, gripper):
     # eval_g alone (compute_derivatives = false) gives the same g
     Gh2, none = ph.eval_host(Z, A.EVAL_G)
     assert none is None
-    assert np.array_equal(Gh2, Gh)
+    check(Gh2, Gh, 1e-13)  # the values-only kernel is a different instantiation: same up to rounding
     _, Jh2 = ph.eval_host(Z, A.EVAL_JAC)
     assert np.array_equal(Jh2, Jh)
 
@@ -187,7 +187,7 @@ def test_full_size_properties(hip, kinova):
     G3 = torch.empty_like(G)
     p.eval_device(Z.data_ptr(), B, A.EVAL_G, G3.data_ptr(), 0, st)
     torch.cuda.synchronize()
-    assert torch.equal(G3, G)
+    assert (G3 - G).abs().max().item() <= 1e-12 * (1 + G.abs().max().item())
     # first-order consistency of J with g along a random direction (linearity check at full size)
     d = torch.randn(B, 7, generator=g, dtype=torch.float64).cuda()
     h = 1e-6
