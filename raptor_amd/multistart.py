@@ -1,0 +1,70 @@
+"""Multi-start sharding: independent decision vectors split across the GPUs of one node.
+
+The reference has no distributed code; its only batch dimension is the set of random
+initial guesses it solves one after another (Examples/Digit/README.md:196-199).  Here the batch of decision
+vectors is block-partitioned over ranks (one process per GPU, contiguous blocks of ceil(B/world) problems,
+SURVEY.md 8e); evaluation needs no communication at all, and afterwards ONE collective gathers a fixed-size
+record per problem -- feasibility, worst constraint violation and, on request, g itself.  Jacobians stay
+resident on the GPU that produced them (a 3.5 GB ring all-gather would be per-link bound on xGMI).
+
+The feasibility rule is the Optimizer's (Optimization/src/Optimizer.cpp:374-378):
+    infeasible  <=>  min(g - g_lb) < -tol  or  min(g_ub - g) < -tol.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of problems owned by `rank` (blocks of ceil(total/world), last ones may be short/empty)."""
+    if total < 0 or world < 1 or not (0 <= rank < world):
+        raise ValueError("bad shard arguments")
+    per = -(-total // world)
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total)
+
+
+def violation(G: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor) -> torch.Tensor:
+    """Worst bound violation per problem, max(0, g_lb - g, g - g_ub) over the rows of each problem."""
+    if G.shape[0] == 0:
+        return G.new_zeros((0,))
+    v = torch.maximum(g_lb - G, G - g_ub).amax(dim=1)
+    return torch.clamp_min(v, 0.0)
+
+
+def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor,
+                     g_ub: torch.Tensor, constr_viol_tol: float = 1e-4, gather_g: bool = False,
+                     group=None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Evaluate this rank's block of `Z_all` with `evaluate` (Z_block -> G_block, on this rank's device) and gather
+    per-problem records on every rank.
+
+    Returns (violation[B], feasible[B] (bool), G[B, m] or None), identical on all ranks.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = Z_all.shape[0]
+    lo, hi = shard_range(B, world, rank)
+    per = -(-B // world) if world > 0 else B
+    G = evaluate(Z_all[lo:hi].contiguous())
+    m = g_lb.numel()
+    dev = G.device
+    # fixed-size record per problem: [violation, g...] padded to the block size so one all_gather suffices
+    width = 1 + (m if gather_g else 0)
+    rec = torch.zeros((per, width), dtype=torch.float64, device=dev)
+    n = hi - lo
+    if n > 0:
+        rec[:n, 0] = violation(G, g_lb.to(dev), g_ub.to(dev))
+        if gather_g:
+            rec[:n, 1:] = G
+    if world > 1:
+        out = torch.empty((world * per, width), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, rec, group=group)
+    else:
+        out = rec
+    out = out[:B]
+    viol = out[:, 0]
+    return viol, viol <= constr_viol_tol, (out[:, 1:] if gather_g else None)
