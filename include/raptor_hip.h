@@ -95,6 +95,33 @@ typedef struct raptor_kinova_desc {
     const double* torque_limits_buffer;  /* [7] N m,  NULL = 0                                  */
 } raptor_kinova_desc;
 
+/*
+ * Floating-base robot whose six base joints are made dependent by a planted stance foot: the arguments of
+ * TalosSingleStepOptimizer::set_parameters / G1SingleStepOptimizer::set_parameters that reach the hot path
+ * (Examples/Talos/src/TalosSingleStepOptimizer.cpp:17-124, TalosDynamicsConstraints.cpp:6-42, same for Unitree-G1).
+ * Blocks built: [torque limits N*Nact | joint limits N*nv | contact N*7]
+ * (TorqueLimits, ConstrainedJointLimits, RectangleSurfaceContactConstraints; the robot-specific "customized" and
+ * periodicity blocks are not built yet).
+ */
+typedef struct raptor_legged_desc {
+    raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = num_independent                                 */
+    int extra_variables;            /* appended to varLength: NUM_JOINTS + NUM_DEPENDENT_JOINTS (v_reset, lambda_reset) */
+    int num_dependent;              /* 6                                                                         */
+    const int* dependent_ids;       /* [num_dependent]   model.getJointId(name) - 1 of Px,Py,Pz,Rx,Ry,Rz          */
+    int num_independent;
+    const int* independent_ids;     /* [num_independent] model.getJointId(name) - 1 of the actuated joints        */
+    int fk_start_joint;             /* model.getJointId("Rz")  (TalosDynamicsConstraints.cpp:214)                  */
+    int contact_joint_id;           /* model.getJointId(LEFT_FOOT_NAME or RIGHT_FOOT_NAME)                        */
+    double stance_foot_endT_p[3];   /* stance_foot_endT.p      (TalosDynamicsConstraints.cpp:34)                   */
+    double stance_foot_T_des_R[9];  /* stance_foot_T_des.R row-major (default identity)                            */
+    double stance_foot_T_des_p[3];
+    const double* torque_limits_lower; /* [num_independent] */
+    const double* torque_limits_upper;
+    const double* joint_limits_lower;  /* [nv] */
+    const double* joint_limits_upper;
+    double mu, gamma, Lx, Ly;       /* rectangleContactSurfaceParams(MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH)           */
+} raptor_legged_desc;
+
 typedef struct raptor_model raptor_model;     /* opaque */
 typedef struct raptor_problem raptor_problem; /* opaque */
 
@@ -117,6 +144,16 @@ int raptor_id_problem_create(const raptor_model* model, const raptor_traj_desc* 
 /* KinovaOptimizer::set_parameters: blocks [joint limits | velocity limits | torque limits | obstacles]
  * (KinovaOptimizer.cpp:82-109). */
 int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_desc* desc, raptor_problem** out);
+
+/* TalosSingleStepOptimizer / G1SingleStepOptimizer set_parameters: ConstrainedInverseDynamics + the three blocks above
+ * (KinematicsDynamics/src/ConstrainedInverseDynamics.cpp:45-184, DynamicsConstraints.cpp:36-103). */
+int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_desc* desc, raptor_problem** out);
+
+/* ConstrainedInverseDynamics::compute results per sample, host buffers (ConstrainedInverseDynamics.h:44-56); any may be NULL:
+ *   q, v, a [B][N][nv] (dependent joints filled in), tau [B][N][Nact], lambda [B][N][n_dep],
+ *   ptau_pz [B][N][Nact][n], plambda_pz [B][N][n_dep][n]  (row-major) */
+int raptor_constrained_id_eval_host(raptor_problem* problem, const double* Z, int B, double* q, double* v, double* a,
+                                    double* tau, double* lambda, double* ptau_pz, double* plambda_pz);
 
 void raptor_problem_destroy(raptor_problem* problem);
 

@@ -966,11 +966,15 @@ struct KinovaCustomizedConstraints : Constraints {
     }
 };
 
+#include "legged_oracle.inc"
+
 // ------------------------------------------------------------------ problem = Optimizer's constraint list
 struct Problem {
     Model model;
     Trajectory traj;
     InverseDynamics id;
+    ContactDynamicsConstraints dc;
+    ConstrainedInverseDynamics cid;
     std::vector<std::unique_ptr<Constraints>> cons;  // constraintsPtrVec_ order
     int n = 0, m = 0;
     std::vector<int> offsets;
@@ -1264,6 +1268,88 @@ int oracle_kinova_problem_create(const raptor_model* model, const raptor_kinova_
                                                         d->box_size, d->include_gripper != 0, d->collision_buffer));  // :102-109
     p.finish();
     *out = pr.release();
+    ORACLE_CATCH
+}
+
+int oracle_legged_problem_create(const raptor_model* model, const raptor_legged_desc* d, raptor_problem** out) {
+    ORACLE_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    std::unique_ptr<raptor_problem> pr(new raptor_problem());
+    Problem& p = pr->p;
+    p.model = model->m;
+    const int nv = p.model.nv;
+    if (d->traj.type != RAPTOR_TRAJ_BEZIER) throw std::invalid_argument("single-step optimizers use BezierCurves");
+    p.traj.init(&d->traj);
+    if (d->extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
+    p.traj.varLength += d->extra_variables;  // TalosSingleStepOptimizer.cpp:50-51
+    p.traj.pq_pz.assign(p.traj.N, MatX(p.traj.Nact, p.traj.varLength));
+    p.traj.pq_d_pz = p.traj.pq_pz;
+    p.traj.pq_dd_pz = p.traj.pq_pz;
+    if (d->num_dependent != 6) throw std::invalid_argument("contact constraint: six dependent joints expected");
+    if (d->num_independent != p.traj.Nact || d->num_dependent + d->num_independent != nv)
+        throw std::invalid_argument("Trajectory and DynamicsConstraints must have the same number of actuated joints");
+    ContactDynamicsConstraints& dc = p.dc;
+    dc.model = &p.model;
+    dc.fk.model = &p.model;
+    dc.nv = nv;
+    dc.nd = d->num_dependent;
+    dc.ni = d->num_independent;
+    dc.dep.assign(d->dependent_ids, d->dependent_ids + dc.nd);
+    dc.ind.assign(d->independent_ids, d->independent_ids + dc.ni);
+    std::vector<int> seen(nv, 0);
+    for (int id : dc.dep) { if (id < 0 || id >= nv || seen[id]++) throw std::invalid_argument("bad dependent joint id"); }
+    for (int id : dc.ind) { if (id < 0 || id >= nv || seen[id]++) throw std::invalid_argument("bad independent joint id"); }
+    dc.fk_start = d->fk_start_joint;
+    dc.contact_joint_id = d->contact_joint_id;
+    if (dc.contact_joint_id < 1 || dc.contact_joint_id > nv || dc.fk_start < 0 || dc.fk_start > nv)
+        throw std::runtime_error("Can not find joint");
+    dc.stance_foot_endT = Transform(Vec3(d->stance_foot_endT_p[0], d->stance_foot_endT_p[1], d->stance_foot_endT_p[2]));
+    Mat3 Rd;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Rd(r, c) = d->stance_foot_T_des_R[3 * r + c];
+    dc.stance_foot_T_des = Transform(Rd, Vec3(d->stance_foot_T_des_p[0], d->stance_foot_T_des_p[1], d->stance_foot_T_des_p[2]));
+    p.cid.model = &p.model;
+    p.cid.traj = &p.traj;
+    p.cid.dc = &p.dc;
+    VecX tl(d->torque_limits_lower, d->torque_limits_lower + dc.ni), tu(d->torque_limits_upper, d->torque_limits_upper + dc.ni);
+    VecX jl(d->joint_limits_lower, d->joint_limits_lower + nv), ju(d->joint_limits_upper, d->joint_limits_upper + nv);
+    p.cons.emplace_back(new ConstrainedTorqueLimits(&p.cid, tl, tu));                                   // TalosSingleStepOptimizer.cpp:69-73
+    p.cons.emplace_back(new ConstrainedJointLimits(&p.cid, jl, ju));                                    // :82-86
+    p.cons.emplace_back(new RectangleSurfaceContactConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly)); // :89-92
+    p.finish();
+    *out = pr.release();
+    ORACLE_CATCH
+}
+
+int oracle_constrained_id_eval_host(raptor_problem* pr, const double* Z, int B, double* q, double* v, double* a,
+                                    double* tau, double* lambda, double* ptau_pz, double* plambda_pz) {
+    ORACLE_TRY
+    if (!pr || !Z) throw std::invalid_argument("null argument");
+    Problem& p = pr->p;
+    if (p.cid.dc == nullptr) throw std::runtime_error("dcPtr_ is not defined yet!");
+    const int nv = p.model.nv, N = p.traj.N, n = p.n, ni = p.dc.ni, nd = p.dc.nd;
+    const bool deriv = ptau_pz != nullptr || plambda_pz != nullptr;
+    for (int b = 0; b < B; b++) {
+        p.cid.compute(Z + (size_t)b * n, deriv);
+        for (int i = 0; i < N; i++) {
+            const size_t e = (size_t)b * N + i;
+            for (int j = 0; j < nv; j++) {
+                if (q) q[e * nv + j] = p.cid.q[i][j];
+                if (v) v[e * nv + j] = p.cid.v[i][j];
+                if (a) a[e * nv + j] = p.cid.a[i][j];
+            }
+            for (int j = 0; j < ni; j++) {
+                if (tau) tau[e * ni + j] = p.cid.tau[i][j];
+                if (ptau_pz)
+                    for (int c = 0; c < n; c++) ptau_pz[(e * ni + j) * n + c] = p.cid.ptau_pz[i](j, c);
+            }
+            for (int j = 0; j < nd; j++) {
+                if (lambda) lambda[e * nd + j] = p.cid.lambda[i][j];
+                if (plambda_pz)
+                    for (int c = 0; c < n; c++) plambda_pz[(e * nd + j) * n + c] = p.cid.plambda_pz[i](j, c);
+            }
+        }
+    }
     ORACLE_CATCH
 }
 

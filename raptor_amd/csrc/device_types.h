@@ -55,6 +55,37 @@ struct DevBox {
     double size[3];
 };
 
+// Floating-base robot with a planted stance foot, re-rooted at the stance-foot link (legged_kernel.h).
+// Bodies are numbered in DFS pre-order from that root, so subtree(g) = [g, body_end[g]).
+#define RAPTOR_LEG_MAX_BODIES 32
+#define RAPTOR_LEG_MAX_DEPTH 20
+#define RAPTOR_LEG_MAX_IND 12
+struct DevLegged {
+    int nb;                                   // bodies (links that carry dynamics), body 0 = stance-foot link
+    int ni, nd, nv, K;                        // independent / dependent joints, model nv, degree + 1
+    int body_link[RAPTOR_LEG_MAX_BODIES];     // original link (= joint) index whose inertia the body carries
+    int body_joint[RAPTOR_LEG_MAX_BODIES];    // original joint connecting the body to its re-rooted parent (-1: root)
+    int body_rev[RAPTOR_LEG_MAX_BODIES];      // 1: that joint is crossed child -> parent (axis flips sign)
+    int body_rparent[RAPTOR_LEG_MAX_BODIES];
+    int body_end[RAPTOR_LEG_MAX_BODIES];
+    int body_depth[RAPTOR_LEG_MAX_BODIES];
+    int body_traj[RAPTOR_LEG_MAX_BODIES];     // trajectory index (0..ni-1) driving the joint, -1: none
+    int path[RAPTOR_LEG_MAX_BODIES][RAPTOR_LEG_MAX_DEPTH];  // path[g][d-1] = ancestor of g at depth d (d = 1..depth)
+    int ind_body[RAPTOR_LEG_MAX_IND];         // body whose joint is independent joint t
+    int ind_joint[RAPTOR_LEG_MAX_IND];        // model joint index of independent joint t
+    int dep_joint[RAPTOR_MAX_NV];             // model joint index of dependent joint d
+    int joint_ind[RAPTOR_MAX_NV];             // model joint -> independent index or -1
+    int joint_dep[RAPTOR_MAX_NV];             // model joint -> dependent index or -1
+    int torso_body;                           // body carried by the last floating-base joint
+    double R0[9], o0[3];                      // world pose of the root body frame: T_des * endT^-1
+    double Ades[9];                           // inverse of d(rpy)/d(omega) at R_des; lambda_rot = Ades^T n_p
+    double p_foot[3];                         // contact point (stance_foot_T_des.p)
+    double mu, gamma, Lx, Ly;                 // RectangleSurfaceContactConstraints
+    int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
+    // per-sample-eval record written by the core kernel (doubles)
+    int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_stride;
+};
+
 // where each constraint block of this problem starts in the Optimizer's row order (-1: block absent)
 struct DevLayout {
     int m;        // rows per decision vector

@@ -1,0 +1,478 @@
+// K_legged : ConstrainedInverseDynamics + TorqueLimits / ConstrainedJointLimits / RectangleSurfaceContactConstraints
+// for floating-base robots with a planted stance foot (Talos, Unitree-G1; reference:
+// KinematicsDynamics/src/ConstrainedInverseDynamics.cpp:45-184, DynamicsConstraints.cpp:36-103,
+// Examples/Talos/src/TalosDynamicsConstraints.cpp:208-350, Constraints/src/{ConstrainedJointLimits,
+// RectangleSurfaceContactConstraints,TorqueLimits}.cpp).
+//
+// MI355X design -- NOT the reference's algorithm order.  The reference fills the six floating-base coordinates from the
+// stance-foot constraint c(q) = 0, builds J, P_dep = -J_dep^-1 J_indep and six derivative blocks from FK Hessians and
+// third-order tensors, runs the floating-base RNEA derivatives (18 x 18), solves J_dep^T lambda = tau_dep and chains
+// ~10 dense products per sample.  On the constraint manifold all of that is the dynamics of a FIXED-BASE tree rooted
+// at the stance-foot link:
+//     tau_indep               = joint torques of the re-rooted tree (principle of virtual work: G^T tau_full),
+//     lambda (contact wrench) = total root wrench taken about the foot point, RPY rows through A_des = (d rpy/d omega)^-1,
+//     d(tau, lambda)/dz       = analytic world-frame tree derivatives (same identities as kinova_kernel.h),
+//     q_dep, P_dep            = pose / velocity map of the torso body seen from the foot.
+// No 6x6 solve, no FK tensors; identical results (numpy model: scripts/proto_rerooted.py agrees with the oracle's
+// literal restatement to 1e-15).
+//
+// Two kernels:
+//   legged_core_kernel  : LG lanes per sample-eval (lane = body of the re-rooted tree, DFS pre-order so that a subtree
+//                         is a lane range and composites are suffix-scan differences on wave shuffles).  Writes the
+//                         g rows and a compact per-sample record: D_q, D_v, D_a (ni x ni), d lambda (6 x ni x 3), P_dep.
+//   legged_expand_kernel: streams the Jacobian rows out in Optimizer order, 16 bytes per lane, from those records:
+//                         row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k   (BezierCurves.cpp:165-169)
+//                         -- this kernel is the HBM-bound one (8 * (n + 1) bytes per row).
+#ifndef RAPTOR_LEGGED_KERNEL_H
+#define RAPTOR_LEGGED_KERNEL_H
+
+#include "kernels.h"
+#include "kinova_kernel.h"
+
+#define LEG_BLOCK 64      // core kernel: one wavefront per workgroup (no workgroup barrier anywhere)
+#define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
+
+template <int LG>
+struct LegLds {
+    static constexpr int X = 0;                 // phase-0 exchange: qd, qdd, cos q, sin q, q per body
+    static constexpr int V = LG * 5;            // per-joint vectors
+    static constexpr int STRIDE = V + LG * LEG_VEC + 2;
+};
+
+// Utils::wrapToPi (Utils/include/Utils.h:59-68)
+RD double wrap_to_pi(double a) {
+    while (a > M_PI) a -= 2.0 * M_PI;
+    while (a < -M_PI) a += 2.0 * M_PI;
+    return a;
+}
+// HigherOrderDerivatives.h:10-38
+__host__ __device__ inline double safe_asin(double x) { return x > 1.0 ? M_PI_2 : (x < -1.0 ? -M_PI_2 : asin(x)); }
+__host__ __device__ inline double safe_dasin(double x) { return x >= 1.0 ? 1e10 : (x <= -1.0 ? -1e10 : 1.0 / sqrt(1.0 - x * x)); }
+
+// d(roll, pitch, yaw)/dt of Transform::getRPY (Transform.cpp:379-390) for a frame R rotating with world-frame angular
+// velocity w: the rows of ForwardKinematicsSolver::getRPYJacobian (ForwardKinematics.cpp:358-384) with dR = [w]x R.
+__host__ __device__ inline void rpy_rates(const double* R, const double* w, double* out) {
+    const double dR02 = -w[2] * R[5] + w[1] * R[8];
+    const double dR00 = -w[2] * R[3] + w[1] * R[6];
+    const double dR01 = -w[2] * R[4] + w[1] * R[7];
+    const double dR12 = w[2] * R[2] - w[0] * R[8];
+    const double dR22 = -w[1] * R[2] + w[0] * R[5];
+    const double rollDenom = R[5] * R[5] + R[8] * R[8];
+    const double yawDenom = R[0] * R[0] + R[1] * R[1];
+    out[0] = (R[5] * dR22 - R[8] * dR12) / rollDenom;
+    out[1] = safe_dasin(R[2]) * dR02;
+    out[2] = (R[1] * dR00 - R[0] * dR01) / yawDenom;
+}
+RD V3 rpy_rates(const M3& R, V3 w) {
+    const double wv[3] = {w.x, w.y, w.z};
+    double o[3];
+    rpy_rates(R.m, wv, o);
+    return v3(o[0], o[1], o[2]);
+}
+
+RD M3 mulBT(const M3& A, const double* B) {  // A * B^T, B row-major 3x3
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C.m[3 * i + j] = A.m[3 * i] * B[3 * j] + A.m[3 * i + 1] * B[3 * j + 1] + A.m[3 * i + 2] * B[3 * j + 2];
+    return C;
+}
+
+// RectangleSurfaceContactConstraints.cpp:52-93: row r of the 7 contact rows as a linear map of d(lambda.tail(6)) = p
+RD double contact_row(int r, const double* lam, const double* p, double mu, double gamma, double Lx, double Ly) {
+    switch (r) {
+        case 0: return p[2];
+        case 1: {
+            const double ff = sqrt(lam[0] * lam[0] + lam[1] * lam[1]);
+            return (ff <= 1e-8) ? -mu * p[2] : (lam[0] * p[0] + lam[1] * p[1]) / ff - mu * p[2];
+        }
+        case 2: return sign_eps(lam[5]) * p[5] - gamma * p[2];
+        case 3: return p[3] - Lx * p[2];
+        case 4: return -Lx * p[2] - p[3];
+        case 5: return p[4] - Ly * p[2];
+        default: return -Ly * p[2] - p[4];
+    }
+}
+
+template <int LG, bool DERIV>
+__global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
+    const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
+    const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
+    double* __restrict__ G, double* __restrict__ core) {
+    extern __shared__ double lds[];
+    using LL = LegLds<LG>;
+    constexpr int EPB = LEG_BLOCK / LG;
+    const int tid = threadIdx.x;
+    const int g = tid & (LG - 1);
+    const int eg = tid / LG;
+    const long long e = (long long)blockIdx.x * EPB + eg;
+    if (e >= E) return;  // whole lane groups leave together
+    double* sl = lds + eg * LL::STRIDE;
+    const int N = T->N;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    const double* z = Z + b * L.n;
+    const size_t rowbase = (size_t)b * L.m;
+    double* rec = core + (size_t)e * Q->c_stride;
+    const int nb = Q->nb, ni = Q->ni, nv = Q->nv;
+    const bool has_body = g < nb;
+    const bool has_joint = has_body && g > 0;
+    const int gb = has_body ? g : 0;
+    const int jnt = has_joint ? Q->body_joint[gb] : 0;
+    const int tj = has_joint ? Q->body_traj[gb] : -1;
+    const int gend = has_body ? Q->body_end[gb] : LG;
+
+    // ---- phase 0: this body's joint: trajectory value and sincos ----
+    double q = 0.0, qd = 0.0, qdd = 0.0, sq = 0.0, cq = 1.0;
+    if (tj >= 0) {
+        traj_joint(T, basis, z, i, tj, q, qd, qdd);
+        sincos(q, &sq, &cq);
+    }
+    if (has_joint) {
+        double* x = sl + LL::X + g * 5;
+        x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
+    }
+    wave_sync();
+
+    // ---- phase A: world-frame kinematics from the planted foot out to this body (per-lane path) ----
+    M3 Rw;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.m[k] = Q->R0[k];
+    V3 ow = v3(Q->o0[0], Q->o0[1], Q->o0[2]);
+    SV v = sv_zero(), vprev = sv_zero();
+    const SV a0 = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
+    SV a = a0;
+    SV s = sv_zero();
+    const int depth = has_body ? Q->body_depth[gb] : 0;
+#pragma unroll 1
+    for (int d = 0; d < depth; d++) {
+        const int l = Q->path[gb][d];
+        const int j = Q->body_joint[l];
+        const double* x = sl + LL::X + l * 5;
+        const double lqd = x[0], lqdd = x[1], lcq = x[2], lsq = x[3], lq = x[4];
+        const int jt = M->jtype[j];
+        const V3 pl = v3(M->plp[j][0], M->plp[j][1], M->plp[j][2]);
+        M3 R;
+        V3 o;
+        if (!Q->body_rev[l]) {
+            const M3 A = mul(Rw, M->plR[j]);
+            o = ow + mul(Rw, pl);
+            joint_world(jt, lq, lcq, lsq, A, R, o, s);
+        } else {  // crossing the joint from its child link to its parent link: undo the joint, then the placement
+            M3 A;
+            V3 oj = ow;
+            joint_world(jt, -lq, lcq, -lsq, Rw, A, oj, s);
+            s = s * -1.0;  // the generalized coordinate keeps its meaning, the successor body is on the other side
+            R = mulBT(A, M->plR[j]);
+            o = oj - mul(R, pl);
+        }
+        const SV sqd = s * lqd;
+        vprev = v;
+        a = a + s * lqdd + crm(v, sqd);
+        v = v + sqd;
+        Rw = R;
+        ow = o;
+    }
+    const SV sd = crm(vprev, s);
+
+    // ---- phase B: this body's inertia, momentum, wrench, Coriolis block (world frame, about the origin) ----
+    InertiaO I;
+    SV h, f;
+    double Qt[6];
+    {
+        const int link = Q->body_link[gb];
+        Inertia Ic;
+        const V3 c = ow + mul(Rw, v3(M->lever[link][0], M->lever[link][1], M->lever[link][2]));
+        rotate_inertia(Rw, M->Ic[link], Ic);
+        const double m = has_body ? M->mass[link] : 0.0;
+        const double keep = has_body ? 1.0 : 0.0;
+        I.m = m;
+        I.hv = c * m;
+        const double cc = dot(c, c);
+        I.xx = keep * Ic.xx + m * (cc - c.x * c.x);
+        I.yy = keep * Ic.yy + m * (cc - c.y * c.y);
+        I.zz = keep * Ic.zz + m * (cc - c.z * c.z);
+        I.xy = keep * Ic.xy - m * c.x * c.y;
+        I.xz = keep * Ic.xz - m * c.x * c.z;
+        I.yz = keep * Ic.yz - m * c.y * c.z;
+        h = applyO(I, v);
+        f = applyO(I, a) + crf(v, h);
+        if (DERIV) {
+            const V3 w = v.a, u = v.l;
+            const V3 c0 = cross(w, v3(I.xx, I.xy, I.xz));
+            const V3 c1 = cross(w, v3(I.xy, I.yy, I.yz));
+            const V3 c2 = cross(w, v3(I.xz, I.yz, I.zz));
+            const double uh = 2.0 * dot(u, I.hv);
+            Qt[0] = 2.0 * c0.x - 2.0 * I.hv.x * u.x + uh;
+            Qt[1] = c1.x + c0.y - (I.hv.x * u.y + u.x * I.hv.y);
+            Qt[2] = c2.x + c0.z - (I.hv.x * u.z + u.x * I.hv.z);
+            Qt[3] = 2.0 * c1.y - 2.0 * I.hv.y * u.y + uh;
+            Qt[4] = c2.y + c1.z - (I.hv.y * u.z + u.y * I.hv.z);
+            Qt[5] = 2.0 * c2.z - 2.0 * I.hv.z * u.z + uh;
+        }
+    }
+
+    // ---- phase C: subtree composites = suffix scan over the DFS order minus the suffix at the subtree's end ----
+    SV F = f, H = h;
+    {
+        const int src = gend & (LG - 1);
+        const bool cut = gend < LG;
+#define SCAN(x) { const double y_ = __shfl_down(x, d, LG); if (take) x += y_; }
+#define CUT(x) { const double y_ = __shfl(x, src, LG); if (cut) x -= y_; }
+#pragma unroll
+        for (int d = 1; d < LG; d <<= 1) {
+            const bool take = (g + d) < LG;
+            SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
+            if (DERIV) {
+                SCAN(H.a.x) SCAN(H.a.y) SCAN(H.a.z) SCAN(H.l.x) SCAN(H.l.y) SCAN(H.l.z)
+                SCAN(I.m) SCAN(I.hv.x) SCAN(I.hv.y) SCAN(I.hv.z)
+                SCAN(I.xx) SCAN(I.xy) SCAN(I.xz) SCAN(I.yy) SCAN(I.yz) SCAN(I.zz)
+                SCAN(Qt[0]) SCAN(Qt[1]) SCAN(Qt[2]) SCAN(Qt[3]) SCAN(Qt[4]) SCAN(Qt[5])
+            }
+        }
+        CUT(F.a.x) CUT(F.a.y) CUT(F.a.z) CUT(F.l.x) CUT(F.l.y) CUT(F.l.z)
+        if (DERIV) {
+            CUT(H.a.x) CUT(H.a.y) CUT(H.a.z) CUT(H.l.x) CUT(H.l.y) CUT(H.l.z)
+            CUT(I.m) CUT(I.hv.x) CUT(I.hv.y) CUT(I.hv.z)
+            CUT(I.xx) CUT(I.xy) CUT(I.xz) CUT(I.yy) CUT(I.yz) CUT(I.zz)
+            CUT(Qt[0]) CUT(Qt[1]) CUT(Qt[2]) CUT(Qt[3]) CUT(Qt[4]) CUT(Qt[5])
+        }
+#undef SCAN
+#undef CUT
+    }
+
+    // ---- phase D: values.  tau rows, q rows, contact rows; the same numbers go to the compact record ----
+    const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
+    const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
+    if (has_joint) {
+        // ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
+        const double tau = dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd;
+        rec[Q->c_q + jnt] = q;
+        rec[Q->c_v + jnt] = qd;
+        rec[Q->c_a + jnt] = qdd;
+        if (tj >= 0) {
+            rec[Q->c_tau + tj] = tau;
+            if (G != nullptr) {
+                G[rowbase + Q->off_tau + (size_t)i * ni + tj] = tau;                 // TorqueLimits.cpp:30-34
+                G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);        // ConstrainedJointLimits.cpp:57
+            }
+        }
+    }
+    if (g == 0) {  // root: contact wrench lambda = [f ; A_des^T (n - p x f)]   (== J_dep^-T tau_dep, ConstrainedInverseDynamics.cpp:154)
+        const V3 np = F.a - cross(pf, F.l);
+        double lam[6] = {F.l.x, F.l.y, F.l.z,
+                         Q->Ades[0] * np.x + Q->Ades[3] * np.y + Q->Ades[6] * np.z,
+                         Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
+                         Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) rec[Q->c_lam + k] = lam[k];
+        if (G != nullptr) {  // RectangleSurfaceContactConstraints.cpp:35-50
+            double* gc = G + rowbase + Q->off_contact + (size_t)i * 7;
+            const double ff = sqrt(lam[0] * lam[0] + lam[1] * lam[1]);
+            gc[0] = lam[2];
+            gc[1] = ff - mu * lam[2];
+            gc[2] = fabs(lam[5]) - gam * lam[2];
+            gc[3] = lam[3] - Lx * lam[2];
+            gc[4] = -Lx * lam[2] - lam[3];
+            gc[5] = lam[4] - Ly * lam[2];
+            gc[6] = -Ly * lam[2] - lam[4];
+        }
+    }
+    if (has_body && g == Q->torso_body) {
+        // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
+        const V3 rpy = v3(atan2(-Rw.m[5], Rw.m[8]), safe_asin(Rw.m[2]), atan2(-Rw.m[1], Rw.m[0]));
+        const V3 pd = v.l + cross(v.a, ow);
+        const V3 rd = rpy_rates(Rw, v.a);
+        const V3 al = a.a;  // gravity enters only the linear part of a0
+        const V3 pdd = (a.l - a0.l) + cross(al, ow) + cross(v.a, pd);
+        double sr, cr;
+        sincos(rpy.x, &sr, &cr);
+        const V3 a1 = v3(1, 0, 0), a2 = v3(0, cr, sr), a3 = col(Rw, 2);
+        const V3 a2d = cross(a1 * rd.x, a2), a3d = cross(a1 * rd.x + a2 * rd.y, a3);
+        const V3 rdd = rpy_rates(Rw, al - a2d * rd.y - a3d * rd.z);
+        const double qv[6] = {ow.x, ow.y, ow.z, rpy.x, rpy.y, rpy.z};
+        const double vv[6] = {pd.x, pd.y, pd.z, rd.x, rd.y, rd.z};
+        const double av[6] = {pdd.x, pdd.y, pdd.z, rdd.x, rdd.y, rdd.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int dj = Q->dep_joint[k];
+            rec[Q->c_q + dj] = qv[k];
+            rec[Q->c_v + dj] = vv[k];
+            rec[Q->c_a + dj] = av[k];
+            if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + dj] = wrap_to_pi(qv[k]);
+        }
+    }
+    if (!DERIV) return;
+
+    // ---- phase E: per-joint 6-vectors of the analytic derivative ----
+    const SV psi = crm(a, s) + crm(v, sd);
+    const SV IS = applyO(I, s);
+    SV BtS;
+    {
+        const SV IdS = applyO(I, sd);
+        const SV Ipsi = applyO(I, psi);
+        const SV QS = applyQ(Qt, H.l, s);
+        const SV QdS = applyQ(Qt, H.l, sd);
+        const SV HS = crf(s, H);
+        const SV HdS = crf(sd, H);
+        const SV cF = crf(s, F);
+        BtS = QS - HS;
+        const SV cv = IdS * 2.0 + QS + HS;
+        const SV cq_ = Ipsi + QdS + HdS + cF;
+        if (has_joint) {
+            double* vv = sl + LL::V + g * LEG_VEC;
+            lds_put(vv, s); lds_put(vv + 6, sd); lds_put(vv + 12, psi);
+            lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
+        }
+    }
+    // the torso's pose is needed for P_dep: broadcast from the torso's lane (12 shuffles)
+    M3 Rt;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rt.m[k] = __shfl(Rw.m[k], Q->torso_body, LG);
+    const V3 ot = v3(__shfl(ow.x, Q->torso_body, LG), __shfl(ow.y, Q->torso_body, LG), __shfl(ow.z, Q->torso_body, LG));
+    wave_sync();
+
+    // P_dep column of this joint (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246): the torso moves with this
+    // joint iff the torso body is in this joint's subtree
+    if (tj >= 0) {
+        const bool moves = Q->torso_body >= g && Q->torso_body < gend;
+        const V3 lin = s.l + cross(s.a, ot);
+        const V3 rot = rpy_rates(Rt, s.a);
+        const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + tj] = moves ? pc[k] : 0.0;
+    }
+
+    // ---- phase F: D_q, D_v, D_a (rows = this lane's joint, columns = independent joints) and d(lambda) ----
+#pragma unroll 1
+    for (int it = 0; it < ni; it++) {
+        const int k = Q->ind_body[it];
+        const int kend = Q->body_end[k];
+        const double* vk = sl + LL::V + k * LEG_VEC;
+        if (tj >= 0) {
+            double dq, dv, da;
+            if (k > g && k < gend) {  // this joint is a strict ancestor of k
+                da = dot(s, lds_sv(vk + 18));
+                dv = dot(s, lds_sv(vk + 24));
+                dq = dot(s, lds_sv(vk + 30));
+            } else if (g >= k && g < kend) {  // k is this joint or one of its ancestors
+                const SV sk = lds_sv(vk), sdk = lds_sv(vk + 6), psik = lds_sv(vk + 12);
+                da = dot(IS, sk);
+                dv = 2.0 * dot(IS, sdk) + dot(BtS, sk);
+                dq = dot(IS, psik) + dot(BtS, sdk);
+                if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
+                    da += M->armature[jnt];
+                    dv += M->damping[jnt];
+                }
+            } else {
+                da = dv = dq = 0.0;
+            }
+            double* D = rec + Q->c_D + (size_t)(tj * 3) * ni + it;
+            D[0] = dq; D[ni] = dv; D[2 * ni] = da;
+        }
+        if (g == 0) {  // d(root wrench) for a unit (q, v, a) change of joint k, mapped like lambda
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                const SV w = lds_sv(vk + (x == 0 ? 30 : (x == 1 ? 24 : 18)));
+                const V3 np = w.a - cross(pf, w.l);
+                const double lm[6] = {w.l.x, w.l.y, w.l.z,
+                                      Q->Ades[0] * np.x + Q->Ades[3] * np.y + Q->Ades[6] * np.z,
+                                      Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
+                                      Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
+#pragma unroll
+                for (int r = 0; r < 6; r++) rec[Q->c_L + (size_t)(r * 3 + x) * ni + it] = lm[r];
+            }
+        }
+    }
+}
+
+// One Jacobian entry of the problem's row r (within one decision vector), column c.
+RD double legged_jac_entry(const DevLegged* __restrict__ Q, const double* __restrict__ basis,
+                           const double* __restrict__ core, long long b, int N, int r, int c) {
+    const int ni = Q->ni, K = Q->K, nv = Q->nv;
+    if (c >= ni * K) return 0.0;  // v_reset / lambda_reset columns never enter these blocks (TalosSingleStepOptimizer.cpp:50-51)
+    const int t = c / K, k = c - t * K;
+    int i, lr, kind;
+    if (r >= Q->off_tau && r < Q->off_tau + N * ni) {
+        kind = 0; i = (r - Q->off_tau) / ni; lr = (r - Q->off_tau) - i * ni;
+    } else if (r >= Q->off_q && r < Q->off_q + N * nv) {
+        kind = 1; i = (r - Q->off_q) / nv; lr = (r - Q->off_q) - i * nv;
+    } else {
+        kind = 2; i = (r - Q->off_contact) / 7; lr = (r - Q->off_contact) - i * 7;
+    }
+    const double* Bs = basis + (size_t)(i * 3) * K + k;
+    const double B0 = Bs[0], B1 = Bs[K], B2 = Bs[2 * K];
+    const double* rec = core + (size_t)(b * N + i) * Q->c_stride;
+    if (kind == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
+        const double* D = rec + Q->c_D + (size_t)(lr * 3) * ni + t;
+        return D[0] * B0 + D[ni] * B1 + D[2 * ni] * B2;
+    }
+    if (kind == 1) {  // ConstrainedJointLimits.cpp:59-68
+        const int ti = Q->joint_ind[lr];
+        if (ti >= 0) return (ti == t) ? B0 : 0.0;
+        return rec[Q->c_P + Q->joint_dep[lr] * ni + t] * B0;
+    }
+    double p[6];  // RectangleSurfaceContactConstraints.cpp:52-93
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++) {
+        const double* Lm = rec + Q->c_L + (size_t)(rr * 3) * ni + t;
+        p[rr] = Lm[0] * B0 + Lm[ni] * B1 + Lm[2 * ni] * B2;
+    }
+    return contact_row(lr, rec + Q->c_lam, p, Q->mu, Q->gamma, Q->Lx, Q->Ly);
+}
+
+// Streams pg_pz out in Optimizer order: each lane owns two adjacent columns of one row (one 16-byte store).
+__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTraj* __restrict__ T,
+                                                                     const DevLegged* __restrict__ Q,
+                                                                     const double* __restrict__ basis, const DevLayout L,
+                                                                     const double* __restrict__ core, const int tiles_per_z,
+                                                                     double* __restrict__ JAC) {
+    const long long b = blockIdx.x / tiles_per_z;
+    const int tile = (int)(blockIdx.x - b * tiles_per_z);
+    const int el = 2 * (tile * RAPTOR_BLOCK + (int)threadIdx.x);
+    const int total = L.m * L.n;
+    if (el >= total) return;
+    const int r = el / L.n, c = el - r * L.n;
+    const int N = T->N;
+    double2 out;
+    out.x = legged_jac_entry(Q, basis, core, b, N, r, c);
+    if (el + 1 >= total) {  // odd m * n: last entry alone
+        JAC[(size_t)b * total + el] = out.x;
+        return;
+    }
+    if (c + 1 < L.n) {
+        out.y = legged_jac_entry(Q, basis, core, b, N, r, c + 1);
+    } else {  // odd n: the pair straddles two rows
+        out.y = legged_jac_entry(Q, basis, core, b, N, r + 1, 0);
+    }
+    *reinterpret_cast<double2*>(JAC + (size_t)b * total + el) = out;
+}
+
+// ConstrainedInverseDynamics::ptau_pz / plambda_pz view for the parity entry point: [B][N][rows][n]
+__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_id_kernel(const DevTraj* __restrict__ T,
+                                                                        const DevLegged* __restrict__ Q,
+                                                                        const double* __restrict__ basis, const int n,
+                                                                        const double* __restrict__ core, const long long total,
+                                                                        const int rows, const int lambda_rows,
+                                                                        double* __restrict__ out) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int c = (int)(w % n);
+    const long long er = w / n;
+    const int lr = (int)(er % rows);
+    const long long e = er / rows;
+    const int ni = Q->ni, K = Q->K;
+    double val = 0.0;
+    if (c < ni * K) {
+        const int t = c / K, k = c - t * K;
+        const int i = (int)(e % T->N);
+        const double* Bs = basis + (size_t)(i * 3) * K + k;
+        const double* rec = core + (size_t)e * Q->c_stride;
+        const double* D = rec + (lambda_rows ? Q->c_L : Q->c_D) + (size_t)(lr * 3) * ni + t;
+        val = D[0] * Bs[0] + D[ni] * Bs[K] + D[2 * ni] * Bs[2 * K];
+    }
+    out[w] = val;
+}
+
+#endif

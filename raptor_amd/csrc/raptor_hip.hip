@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -15,6 +16,7 @@
 #include "kernels.h"
 #include "capsule_kernel.h"
 #include "kinova_kernel.h"
+#include "legged_kernel.h"
 
 namespace {
 
@@ -89,7 +91,10 @@ struct raptor_model {
 };
 
 struct raptor_problem {
-    int kind = 0;  // 0: inverse dynamics only, 1: Kinova
+    int kind = 0;  // 0: inverse dynamics only, 1: Kinova, 2: legged (Talos / G1)
+    DevLegged hleg;
+    DevBuf<DevLegged> d_leg;
+    DevBuf<double> s_core;  // per-sample records of the legged core kernel (grown on demand, reused)
     DevModel hmodel;
     DevTraj htraj;
     DevSpheres hspheres;
@@ -293,6 +298,39 @@ void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     HIP_CHECK(hipGetLastError());
 }
 
+// core kernel (values + compact derivative records), then the streaming expansion into pg_pz
+void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st) {
+    const long long E = (long long)B * p.htraj.N;
+    if (E == 0) return;
+    p.s_core.ensure((size_t)E * p.hleg.c_stride);
+    const bool wide = p.hleg.nb > 16;
+    const int LG = wide ? 32 : 16;
+    const int epb = LEG_BLOCK / LG;
+    const size_t lds_bytes = (size_t)epb * (wide ? LegLds<32>::STRIDE : LegLds<16>::STRIDE) * sizeof(double);
+    const unsigned grid = (unsigned)((E + epb - 1) / epb);
+#define LEG_LAUNCH(LGV, DV)                                                                                          \
+    hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
+                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, dG, p.s_core.p)
+    if (wide) {
+        if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
+    } else {
+        if (deriv) LEG_LAUNCH(16, true); else LEG_LAUNCH(16, false);
+    }
+#undef LEG_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st) {
+    launch_legged_core(p, dZ, B, dG, jac, st);
+    if (!jac || B == 0) return;
+    const long long total = (long long)p.layout.m * p.layout.n;
+    const int tiles = (int)((total / 2 + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK);
+    if ((long long)tiles * B > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+    hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)((long long)tiles * B)), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p,
+                       p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, tiles, dJ);
+    HIP_CHECK(hipGetLastError());
+}
+
 void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, double* dG, double* dJ, hipStream_t st) {
     if (!(flags & (RAPTOR_EVAL_G | RAPTOR_EVAL_JAC))) throw std::invalid_argument("flags: nothing to evaluate");
     const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
@@ -307,6 +345,8 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     if (p.kind == 1) {  // Kinova: one fused kernel
         if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
         else launch_kinova<false>(p, dZ, B, dG, nullptr, st);
+    } else if (p.kind == 2) {
+        launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st);
     } else {
         if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
         else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
@@ -487,6 +527,206 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     p->d_spheres.upload(&S, 1);
     p->d_boxes.upload(boxes.data(), boxes.size());
     *out = p.release();
+    API_CATCH
+}
+
+int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_desc* d, raptor_problem** out) {
+    API_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    std::unique_ptr<raptor_problem> p(new raptor_problem());
+    p->kind = 2;
+    p->hmodel = model->h;
+    const DevModel& m = p->hmodel;
+    const int nv = m.nv;
+    if (d->traj.type != RAPTOR_TRAJ_BEZIER) throw std::invalid_argument("single-step optimizers use BezierCurves");
+    std::vector<double> basis, wsum;
+    fill_traj(&d->traj, p->htraj, p->tspan, basis, wsum);
+    if (d->extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
+    p->htraj.varLength += d->extra_variables;  // TalosSingleStepOptimizer.cpp:50-51
+    const int N = p->htraj.N, ni = d->num_independent, nd = d->num_dependent, K = p->htraj.degree + 1;
+    if (nd != 6) throw std::invalid_argument("contact constraint: six dependent joints expected");
+    if (ni != p->htraj.Nact || nd + ni != nv)
+        throw std::invalid_argument("Trajectory and DynamicsConstraints must have the same number of actuated joints");
+    if (!d->dependent_ids || !d->independent_ids || !d->torque_limits_lower || !d->torque_limits_upper ||
+        !d->joint_limits_lower || !d->joint_limits_upper)
+        throw std::invalid_argument("null array");
+    if (ni > RAPTOR_LEG_MAX_IND) throw unsupported_error("legged kernel: at most 12 independent joints");
+    DevLegged& Q = p->hleg;
+    std::memset(&Q, 0, sizeof(Q));
+    Q.ni = ni; Q.nd = nd; Q.nv = nv; Q.K = K;
+    for (int j = 0; j < nv; j++) Q.joint_ind[j] = Q.joint_dep[j] = -1;
+    for (int k = 0; k < nd; k++) {
+        const int id = d->dependent_ids[k];
+        if (id < 0 || id >= nv || Q.joint_dep[id] >= 0) throw std::invalid_argument("bad dependent joint id");
+        Q.joint_dep[id] = k;
+        Q.dep_joint[k] = id;
+    }
+    for (int k = 0; k < ni; k++) {
+        const int id = d->independent_ids[k];
+        if (id < 0 || id >= nv || Q.joint_dep[id] >= 0 || Q.joint_ind[id] >= 0) throw std::invalid_argument("bad independent joint id");
+        Q.joint_ind[id] = k;
+        Q.ind_joint[k] = id;
+    }
+    if (d->contact_joint_id < 1 || d->contact_joint_id > nv || d->fk_start_joint < 0 || d->fk_start_joint > nv)
+        throw std::runtime_error("Can not find joint");
+    // the floating base the closed form of TalosDynamicsConstraints.cpp:208-222 assumes: Px,Py,Pz,Rx,Ry,Rz in a chain
+    // from the world, identity placements, massless intermediate links, no joint-space extras
+    static const int base_types[6] = {4, 5, 6, 1, 2, 3};
+    for (int k = 0; k < 6; k++) {
+        const int id = Q.dep_joint[k];
+        bool ok = m.jtype[id] == base_types[k] && m.parent[id] == (k == 0 ? -1 : Q.dep_joint[k - 1]);
+        for (int t = 0; t < 9; t++) ok = ok && std::fabs(m.plR[id][t] - ((t % 4 == 0) ? 1.0 : 0.0)) < 1e-12;
+        for (int t = 0; t < 3; t++) ok = ok && std::fabs(m.plp[id][t]) < 1e-12;
+        ok = ok && (k == 5 || m.mass[id] == 0.0) && m.armature[id] == 0.0 && m.damping[id] == 0.0;
+        if (!ok) throw unsupported_error("legged kernel: the dependent joints must be a Px,Py,Pz,Rx,Ry,Rz floating base");
+    }
+    const int torso_link = Q.dep_joint[5];
+    if (d->fk_start_joint != torso_link + 1) throw unsupported_error("legged kernel: fk_start_joint must be the last floating-base joint");
+    const int foot_link = d->contact_joint_id - 1;
+    if (Q.joint_ind[foot_link] < 0) throw unsupported_error("legged kernel: the stance foot joint must be an independent joint");
+    for (int j = 0; j < nv; j++)
+        if (Q.joint_dep[j] < 0 && (m.parent[j] < 0 || (Q.joint_dep[m.parent[j]] >= 0 && m.parent[j] != torso_link)))
+            throw unsupported_error("legged kernel: every leg must hang from the last floating-base link");
+
+    // re-root at the stance-foot link: DFS pre-order over the links joined by the non-base joints
+    struct Edge { int joint, other, rev; };
+    std::vector<std::vector<Edge>> adj(nv);
+    for (int j = 0; j < nv; j++) {
+        if (Q.joint_dep[j] >= 0) continue;
+        adj[j].push_back(Edge{j, m.parent[j], 1});
+        adj[m.parent[j]].push_back(Edge{j, j, 0});
+    }
+    int nb = 0;
+    std::function<void(int, int, int, int, int)> visit = [&](int link, int via, int rev, int rparent, int depth) {
+        if (nb >= RAPTOR_LEG_MAX_BODIES) throw unsupported_error("legged kernel: more than 32 bodies");
+        if (depth > RAPTOR_LEG_MAX_DEPTH) throw unsupported_error("legged kernel: tree deeper than 20");
+        const int idx = nb++;
+        Q.body_link[idx] = link;
+        Q.body_joint[idx] = via;
+        Q.body_rev[idx] = rev;
+        Q.body_rparent[idx] = rparent;
+        Q.body_depth[idx] = depth;
+        Q.body_traj[idx] = via >= 0 ? Q.joint_ind[via] : -1;
+        if (via >= 0 && Q.joint_ind[via] < 0) throw unsupported_error("legged kernel: closed-loop dependent joints are not built yet");
+        for (int t = 0; t < depth - 1; t++) Q.path[idx][t] = Q.path[rparent][t];
+        if (depth > 0) Q.path[idx][depth - 1] = idx;
+        if (link == torso_link) Q.torso_body = idx;
+        for (const Edge& e : adj[link])
+            if (e.joint != via) visit(e.other, e.joint, e.rev, idx, depth + 1);
+        Q.body_end[idx] = nb;
+    };
+    visit(foot_link, -1, 0, -1, 0);
+    Q.nb = nb;
+    if (nb != ni + 1) throw unsupported_error("legged kernel: every non-base joint must be reachable from the stance foot");
+    for (int g = 1; g < nb; g++) Q.ind_body[Q.body_traj[g]] = g;
+
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Q.R0[3 * r + c] = d->stance_foot_T_des_R[3 * r + c];
+        Q.p_foot[r] = d->stance_foot_T_des_p[r];
+    }
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int c = 0; c < 3; c++) s += Q.R0[3 * r + c] * d->stance_foot_endT_p[c];
+        Q.o0[r] = Q.p_foot[r] - s;  // T_des * endT^-1 (pure translation end transform, TalosDynamicsConstraints.cpp:34-38)
+    }
+    {   // A_des = W^-1, W = d(rpy)/d(omega) at R_des
+        double W[9];
+        for (int k = 0; k < 3; k++) {
+            double w[3] = {0, 0, 0}, o[3];
+            w[k] = 1.0;
+            rpy_rates(Q.R0, w, o);
+            for (int r = 0; r < 3; r++) W[3 * r + k] = o[r];
+        }
+        const double det = W[0] * (W[4] * W[8] - W[5] * W[7]) - W[1] * (W[3] * W[8] - W[5] * W[6]) + W[2] * (W[3] * W[7] - W[4] * W[6]);
+        if (!(std::fabs(det) > 1e-12) || !std::isfinite(det)) throw std::runtime_error("constraint jacobian is not full rank!");
+        const double id = 1.0 / det;
+        Q.Ades[0] = (W[4] * W[8] - W[5] * W[7]) * id; Q.Ades[1] = (W[2] * W[7] - W[1] * W[8]) * id; Q.Ades[2] = (W[1] * W[5] - W[2] * W[4]) * id;
+        Q.Ades[3] = (W[5] * W[6] - W[3] * W[8]) * id; Q.Ades[4] = (W[0] * W[8] - W[2] * W[6]) * id; Q.Ades[5] = (W[2] * W[3] - W[0] * W[5]) * id;
+        Q.Ades[6] = (W[3] * W[7] - W[4] * W[6]) * id; Q.Ades[7] = (W[1] * W[6] - W[0] * W[7]) * id; Q.Ades[8] = (W[0] * W[4] - W[1] * W[3]) * id;
+    }
+    Q.mu = d->mu; Q.gamma = d->gamma; Q.Lx = d->Lx; Q.Ly = d->Ly;
+
+    // layout, TalosSingleStepOptimizer.cpp:69-92: [torque limits | joint limits | contact]
+    const int rt = N * ni, rq = N * nv, rc = N * 7;
+    Q.off_tau = 0; Q.off_q = rt; Q.off_contact = rt + rq;
+    std::memset(&p->hspheres, 0, sizeof(p->hspheres));
+    p->layout = DevLayout{rt + rq + rc, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
+    p->num_blocks = 3;
+    p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rc;
+    p->g_lb.assign(p->layout.m, 0.0);
+    p->g_ub.assign(p->layout.m, 0.0);
+    for (int i = 0; i < N; i++) {
+        for (int j = 0; j < ni; j++) {  // TorqueLimits.cpp:45-50
+            p->g_lb[i * ni + j] = d->torque_limits_lower[j];
+            p->g_ub[i * ni + j] = d->torque_limits_upper[j];
+        }
+        for (int j = 0; j < nv; j++) {  // ConstrainedJointLimits.cpp:73-78
+            p->g_lb[rt + i * nv + j] = d->joint_limits_lower[j];
+            p->g_ub[rt + i * nv + j] = d->joint_limits_upper[j];
+        }
+        p->g_lb[rt + rq + i * 7] = 0;  // RectangleSurfaceContactConstraints.cpp:97-125
+        p->g_ub[rt + rq + i * 7] = 1e19;
+        for (int k = 1; k < 7; k++) {
+            p->g_lb[rt + rq + i * 7 + k] = -1e19;
+            p->g_ub[rt + rq + i * 7 + k] = 0;
+        }
+    }
+    // compact per-sample record
+    int off = 0;
+    Q.c_tau = off; off += ni;
+    Q.c_lam = off; off += 6;
+    Q.c_q = off; off += nv;
+    Q.c_v = off; off += nv;
+    Q.c_a = off; off += nv;
+    Q.c_D = off; off += ni * 3 * ni;
+    Q.c_L = off; off += 6 * 3 * ni;
+    Q.c_P = off; off += nd * ni;
+    Q.c_stride = (off + 1) & ~1;
+
+    upload_common(*p, basis, wsum);
+    p->d_leg.upload(&Q, 1);
+    *out = p.release();
+    API_CATCH
+}
+
+int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, double* q, double* v, double* a,
+                                    double* tau, double* lambda, double* ptau_pz, double* plambda_pz) {
+    API_TRY
+    if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    if (p->kind != 2) throw std::runtime_error("dcPtr_ is not defined yet!");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    const DevLegged& Q = p->hleg;
+    const int N = p->htraj.N, n = p->layout.n, nv = Q.nv, ni = Q.ni, nd = Q.nd;
+    const bool deriv = ptau_pz != nullptr || plambda_pz != nullptr;
+    const size_t E = (size_t)B * N;
+    p->s_Z.upload(Z, (size_t)B * n);
+    launch_legged_core(*p, p->s_Z.p, B, nullptr, deriv, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<double> rec(E * Q.c_stride);
+    HIP_CHECK(hipMemcpy(rec.data(), p->s_core.p, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < E; e++) {
+        const double* r = rec.data() + e * Q.c_stride;
+        for (int j = 0; j < nv; j++) {
+            if (q) q[e * nv + j] = r[Q.c_q + j];
+            if (v) v[e * nv + j] = r[Q.c_v + j];
+            if (a) a[e * nv + j] = r[Q.c_a + j];
+        }
+        if (tau) for (int j = 0; j < ni; j++) tau[e * ni + j] = r[Q.c_tau + j];
+        if (lambda) for (int j = 0; j < nd; j++) lambda[e * nd + j] = r[Q.c_lam + j];
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        double* dst = pass == 0 ? ptau_pz : plambda_pz;
+        if (!dst) continue;
+        const int rows = pass == 0 ? ni : nd;
+        const long long total = (long long)E * rows * n;
+        p->s_J.ensure((size_t)total);
+        hipLaunchKernelGGL(legged_expand_id_kernel, dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, nullptr, p->d_traj.p,
+                           p->d_leg.p, p->d_basis.p, n, p->s_core.p, total, rows, pass, p->s_J.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(dst, p->s_J.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+    }
     API_CATCH
 }
 

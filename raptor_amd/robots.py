@@ -1,0 +1,118 @@
+"""Robot tables of the reference examples that reach the hot path (the *Constants.h / *DynamicsConstraints.h
+files and the model set-up of the example mains), as plain data for `ProblemHandle.legged`."""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Sequence
+
+import numpy as np
+
+from .urdf import RobotModel, load_urdf, lock_joints
+
+
+@dataclasses.dataclass
+class LeggedConfig:
+    dependent_ids: List[int]
+    independent_ids: List[int]
+    extra_variables: int
+    fk_start_joint: int      # Pinocchio joint id (1-based) of "Rz"
+    contact_joint_id: int    # Pinocchio joint id (1-based) of the stance foot joint
+    stance_foot_endT_p: Sequence[float]
+    stance_foot_T_des_R: np.ndarray
+    stance_foot_T_des_p: Sequence[float]
+    torque_limits_lower: np.ndarray
+    torque_limits_upper: np.ndarray
+    joint_limits_lower: np.ndarray
+    joint_limits_upper: np.ndarray
+    mu: float
+    gamma: float
+    Lx: float
+    Ly: float
+    degree: int = 6
+    T: float = 0.4
+    N: int = 14
+
+
+# ---- Talos: Examples/Talos/include/TalosConstants.h:7-96, TalosDynamicsConstraints.h:14-36 ----
+_TALOS_DEP = ["Px", "Py", "Pz", "Rx", "Ry", "Rz"]
+_TALOS_IND = [f"leg_{s}_{k}_joint" for s in ("left", "right") for k in range(1, 7)]
+_TALOS_JL_LO = [-1000] * 6 + [-0.349065850399, -0.5236, -2.095, 0, -1.309, -0.5236,
+                              -1.57079632679, -0.5236, -2.095, 0, -1.309, -0.5236]
+_TALOS_JL_UP = [1000] * 6 + [1.57079632679, 0.5236, 0.7, 2.618, 0.768, 0.5236,
+                             0.349065850399, 0.5236, 0.7, 2.618, 0.768, 0.5236]
+_TALOS_TL = [100, 160, 160, 300, 160, 100] * 2
+
+
+def talos_model(urdf_path: str) -> RobotModel:
+    """Examples/Talos/TalosSingleStep.cpp:16-25: buildModel, motor dynamics zeroed (gravity stays Pinocchio's -9.81)."""
+    m = load_urdf(urdf_path)
+    m.armature[:] = 0
+    m.damping[:] = 0
+    m.friction[:] = 0
+    return m
+
+
+def talos_config(m: RobotModel, stance_leg: str = "L") -> LeggedConfig:
+    foot = "leg_left_6_joint" if stance_leg in "Ll" else "leg_right_6_joint"
+    return LeggedConfig(
+        dependent_ids=[m.joint_id(n) for n in _TALOS_DEP],
+        independent_ids=[m.joint_id(n) for n in _TALOS_IND],
+        extra_variables=18 + 6,                      # TalosSingleStepOptimizer.cpp:50-51
+        fk_start_joint=m.joint_id("Rz") + 1,
+        contact_joint_id=m.joint_id(foot) + 1,
+        stance_foot_endT_p=[0.0, 0.0, -0.107],       # TalosDynamicsConstraints.cpp:34,38
+        stance_foot_T_des_R=np.eye(3), stance_foot_T_des_p=[0.0, 0.0, 0.0],
+        torque_limits_lower=-np.array(_TALOS_TL, dtype=float), torque_limits_upper=np.array(_TALOS_TL, dtype=float),
+        joint_limits_lower=np.array(_TALOS_JL_LO, dtype=float), joint_limits_upper=np.array(_TALOS_JL_UP, dtype=float),
+        mu=0.7, gamma=0.7, Lx=0.1344, Ly=0.2208,     # MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH
+    )
+
+
+# ---- Unitree-G1: Examples/Unitree-G1/include/G1Constants.h, G1DynamicsConstraints.h:14-36, G1SingleStep.cpp:18-43 ----
+_G1_DEP = ["Px_joint", "Py_joint", "Pz_joint", "Rx_joint", "Ry_joint", "Rz_joint"]
+_G1_IND = [f"{s}_{n}_joint" for s in ("left", "right")
+           for n in ("hip_pitch", "hip_roll", "hip_yaw", "knee", "ankle_pitch", "ankle_roll")]
+
+
+def g1_model(urdf_path: str) -> RobotModel:
+    """G1SingleStep.cpp:18-43.  The ten arm joints (Pinocchio ids 19..28) are locked with buildReducedModel at
+    q_armfixed; the example fills q_armfixed(12),(13),(15),(17),(18),(20), but only entries of LOCKED joints
+    (indices 18..27) matter, i.e. q(18) = -0.2 and q(20) = 0.3 -- reproduced as the code does it, not as its
+    comments say."""
+    full = load_urdf(urdf_path)
+    q_armfixed = np.zeros(full.nv)
+    q_armfixed[[12, 13, 15, 17, 18, 20]] = [0.6, 0.2, 0.3, 0.6, -0.2, 0.3]
+    lock = [full.names[i] for i in range(18, 28)]
+    m = lock_joints(full, lock, {full.names[i]: float(q_armfixed[i]) for i in range(18, 28)})
+    m.armature[:] = 0
+    m.damping[:] = 0
+    m.friction[:] = 0
+    return m
+
+
+def _g1_constants(path_hint: str = ""):
+    # G1Constants.h:12-83.  JOINT_LIMITS_LOWER is missing a comma in the reference ("-0.87267 -0.2618" is one
+    # expression), so it has 17 initialisers and the 18th is value-initialised to 0 (SURVEY.md 8a note).
+    lo = [-1000] * 6 + [-2.5307, -0.5236, -2.7576, -0.087267, -0.87267 - 0.2618,
+                        -2.5307, -2.9671, -2.7576, -0.087267, -0.87267, -0.2618, 0.0]
+    up = [1000] * 6 + [2.8798, 2.9671, 2.7576, 2.8798, 0.5236, 0.2618,
+                       2.8798, 0.5236, 2.7576, 2.8798, 0.5236, 0.2618]
+    tl = [88, 88, 88, 139, 50, 50] * 2
+    return lo, up, tl
+
+
+def g1_config(m: RobotModel, stance_leg: str = "L") -> LeggedConfig:
+    lo, up, tl = _g1_constants()
+    foot = "left_ankle_roll_joint" if stance_leg in "Ll" else "right_ankle_roll_joint"
+    return LeggedConfig(
+        dependent_ids=[m.joint_id(n) for n in _G1_DEP],
+        independent_ids=[m.joint_id(n) for n in _G1_IND],
+        extra_variables=18 + 6,
+        fk_start_joint=m.joint_id("Rz_joint") + 1,
+        contact_joint_id=m.joint_id(foot) + 1,
+        stance_foot_endT_p=[0.035, 0.0, -0.03],      # G1DynamicsConstraints.cpp:34,38
+        stance_foot_T_des_R=np.eye(3), stance_foot_T_des_p=[0.0, 0.0, 0.0],
+        torque_limits_lower=-np.array(tl, dtype=float), torque_limits_upper=np.array(tl, dtype=float),
+        joint_limits_lower=np.array(lo, dtype=float), joint_limits_upper=np.array(up, dtype=float),
+        mu=0.7, gamma=0.7, Lx=0.10, Ly=0.03,
+    )

@@ -1,0 +1,187 @@
+"""numpy model of the legged HIP kernel (re-rooted tree formulation), checked against the oracle.
+
+Stance foot planted => the robot is a fixed-base tree rooted at the stance-foot link.  Bodies are numbered in DFS
+pre-order from that root, so subtree(g) = [g, end[g]).  World-frame spatial algebra (same as the Kinova kernel).
+  tau (actuated)  = joint torques of that tree                      (no P_dep, no lambda solve)
+  lambda (contact)= A_des^T-mapped total wrench at the foot point
+  d/dz            = analytic tree derivatives, column weights (B, dB, ddB)
+Run: python scripts/proto_rerooted.py [talos|g1]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from raptor_amd import _capi as A
+from raptor_amd.urdf import jtype_transform
+from proto_world_derivs import crf, crm, skew
+from proto_legged import build, rpy_rate_matrix
+
+
+def reroot(m, foot_link, first_real_link=5):
+    """DFS pre-order of the links reachable through joints > first_real_link, rooted at foot_link."""
+    n = m.nv
+    adj = {l: [] for l in range(first_real_link, n)}
+    for j in range(first_real_link + 1, n):
+        p = int(m.parent[j])
+        adj[j].append((j, p, True))    # crossing joint j from its child link to its parent link: reversed
+        adj[p].append((j, j, False))   # forward
+    bodies = []  # dict(link, joint, rev, rparent)
+    def visit(link, via_joint, rev, rparent):
+        idx = len(bodies)
+        bodies.append(dict(link=link, joint=via_joint, rev=rev, rparent=rparent))
+        for (j, other, r) in sorted(adj[link]):
+            if j == via_joint:
+                continue
+            visit(other, j, r, idx)
+        bodies[idx]["end"] = len(bodies)
+    visit(foot_link, -1, False, -1)
+    return bodies
+
+
+def axis_of(jt, Aw):
+    aj = abs(jt); sg = 1.0 if jt > 0 else -1.0
+    return sg * Aw[:, (aj - 1) % 3], aj <= 3
+
+
+def rpy_of(R):
+    return np.array([np.arctan2(-R[1, 2], R[2, 2]), np.arcsin(np.clip(R[0, 2], -1, 1)), np.arctan2(-R[0, 1], R[0, 0])])
+
+
+def evaluate(m, cfg, bodies, qj, vj, aj_):
+    """qj, vj, aj_: values indexed by ORIGINAL joint index (only joints > 5 used).  Returns dict."""
+    nb = len(bodies)
+    Rd = np.asarray(cfg.stance_foot_T_des_R, float)
+    pd = np.asarray(cfg.stance_foot_T_des_p, float)
+    pe = np.asarray(cfg.stance_foot_endT_p, float)
+    a0 = np.concatenate([np.zeros(3), -m.gravity])
+    R = [None] * nb; o = [None] * nb; s = [None] * nb; v = [None] * nb; a = [None] * nb
+    sd = [None] * nb; psi = [None] * nb
+    R[0] = Rd.copy(); o[0] = pd - Rd @ pe; v[0] = np.zeros(6); a[0] = a0
+    for g in range(1, nb):
+        b = bodies[g]; p = b["rparent"]; j = b["joint"]; jt = int(m.jtype[j])
+        Rq, _ = jtype_transform(jt, qj[j])
+        if b["rev"]:   # body g is the PARENT link of joint j; body p the child link
+            Aw = R[p] @ Rq.T
+            ax, rot = axis_of(jt, Aw)
+            assert rot
+            oj = o[p]
+            R[g] = Aw @ m.placement_R[j].T
+            o[g] = oj - R[g] @ m.placement_p[j]
+            sj = -np.concatenate([ax, np.cross(oj, ax)])
+        else:
+            Aw = R[p] @ m.placement_R[j]
+            oj = o[p] + R[p] @ m.placement_p[j]
+            ax, rot = axis_of(jt, Aw)
+            assert rot
+            R[g] = Aw @ Rq; o[g] = oj
+            sj = np.concatenate([ax, np.cross(oj, ax)])
+        s[g] = sj
+        v[g] = v[p] + sj * vj[j]
+        sd[g] = crm(v[p], sj)
+        a[g] = a[p] + sj * aj_[j] + sd[g] * vj[j]
+        psi[g] = crm(a[g], sj) + crm(v[g], sd[g])
+    I6 = [None] * nb; h = [None] * nb; f = [None] * nb; Pm = [None] * nb
+    for g in range(nb):
+        l = bodies[g]["link"]
+        c = o[g] + R[g] @ m.lever[l]; mm = m.mass[l]
+        Ic = R[g] @ m.inertia[l] @ R[g].T
+        IO = Ic + mm * skew(c) @ skew(c).T
+        I = np.zeros((6, 6)); I[:3, :3] = IO; I[:3, 3:] = skew(mm * c); I[3:, :3] = -skew(mm * c); I[3:, 3:] = mm * np.eye(3)
+        I6[g] = I; h[g] = I @ v[g]; f[g] = I @ a[g] + crf(v[g], h[g])
+        cm = np.zeros((6, 6)); cm[:3, :3] = skew(v[g][:3]); cm[:3, 3:] = skew(v[g][3:]); cm[3:, 3:] = skew(v[g][:3])
+        Pm[g] = cm @ I
+    # composites by suffix-sum difference (what the kernel does with wave shuffles)
+    def composite(xs):
+        S = [None] * (nb + 1); S[nb] = np.zeros_like(xs[0])
+        for g in range(nb - 1, -1, -1):
+            S[g] = S[g + 1] + xs[g]
+        return [S[g] - S[bodies[g]["end"]] for g in range(nb)]
+    IC = composite(I6); HC = composite(h); F = composite(f); PC = composite(Pm)
+    out = dict(R=R, o=o, s=s)
+    tau = np.zeros(nb)
+    vec = [None] * nb
+    for g in range(1, nb):
+        j = bodies[g]["joint"]
+        tau[g] = s[g] @ F[g] + m.armature[j] * aj_[j] + m.damping[j] * vj[j]
+        Q = PC[g] + PC[g].T
+        IS = IC[g] @ s[g]; IdS = IC[g] @ sd[g]; Ipsi = IC[g] @ psi[g]
+        QS = Q @ s[g]; QdS = Q @ sd[g]; HS = crf(s[g], HC[g]); HdS = crf(sd[g], HC[g]); cF = crf(s[g], F[g])
+        vec[g] = dict(IS=IS, BtS=QS - HS, cv=2 * IdS + QS + HS, cq=Ipsi + QdS + HdS + cF)
+    # tree matrices (rows/cols = bodies 1..nb-1; row 0 reserved for the root wrench, 6-vectors)
+    Cq = np.zeros((nb, nb)); Cv = np.zeros((nb, nb)); Mt = np.zeros((nb, nb))
+    FQ = np.zeros((6, nb)); FV = np.zeros((6, nb)); FA = np.zeros((6, nb))
+    for k in range(1, nb):
+        FQ[:, k] = vec[k]["cq"]; FV[:, k] = vec[k]["cv"]; FA[:, k] = vec[k]["IS"]
+        for j in range(1, nb):
+            if k < j < bodies[k]["end"] or j == k:       # k ancestor-or-equal of j
+                Mt[j, k] = vec[j]["IS"] @ s[k]
+                Cv[j, k] = 2 * vec[j]["IS"] @ sd[k] + vec[j]["BtS"] @ s[k]
+                Cq[j, k] = vec[j]["IS"] @ psi[k] + vec[j]["BtS"] @ sd[k]
+            elif j < k < bodies[j]["end"]:                # j strict ancestor of k
+                Mt[j, k] = s[j] @ vec[k]["IS"]; Cv[j, k] = s[j] @ vec[k]["cv"]; Cq[j, k] = s[j] @ vec[k]["cq"]
+        jk = bodies[k]["joint"]
+        Mt[k, k] += m.armature[jk]; Cv[k, k] += m.damping[jk]
+    out.update(tau=tau, Cq=Cq, Cv=Cv, Mt=Mt, Froot=F[0], FQ=FQ, FV=FV, FA=FA)
+    return out
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "talos"
+    oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
+    N = 5
+    m, cfg, p, keep = build(oracle, which, N)
+    bodies = reroot(m, cfg.contact_joint_id - 1)
+    nb = len(bodies)
+    print(which, "bodies", [(b["link"], b["joint"], int(b["rev"]), b["rparent"], b["end"]) for b in bodies])
+    rng = np.random.default_rng(3)
+    Z = 0.3 * rng.uniform(-1, 1, (1, p.n))
+    ref = p.constrained_id_host(Z, N, m.nv, 12, 6, True)
+    K = cfg.degree + 1
+    # basis from the oracle's trajectory: recover B, dB, ddB by probing unit coefficient vectors
+    basis = np.zeros((N, 3, K))
+    for k in range(K):
+        zz = np.zeros((1, p.n)); zz[0, k] = 1.0
+        qq, qd, qdd = p.trajectory_host(zz, N, 12)
+        basis[:, 0, k] = qq[0, :, 0]; basis[:, 1, k] = qd[0, :, 0]; basis[:, 2, k] = qdd[0, :, 0]
+    ind = cfg.independent_ids
+    body_of_joint = {bodies[g]["joint"]: g for g in range(1, nb)}
+    Ades = np.linalg.inv(rpy_rate_matrix(np.asarray(cfg.stance_foot_T_des_R, float)))
+    pfoot = np.asarray(cfg.stance_foot_T_des_p, float)
+    Xp = np.eye(6); Xp[:3, 3:] = -skew(pfoot)      # moment about the foot point: n - p x f
+    W6 = np.zeros((6, 6)); W6[:3, 3:] = np.eye(3); W6[3:, :3] = Ades.T   # lambda = [f ; Ades^T n_p]
+    L = W6 @ Xp
+    worst = {}
+    def upd(k, x, y):
+        worst[k] = max(worst.get(k, 0), float(np.abs(x - y).max() / (1 + np.abs(y).max())))
+    for i in range(N):
+        coef = Z[0, :12 * K].reshape(12, K)
+        qa = coef @ basis[i, 0]; va = coef @ basis[i, 1]; aa = coef @ basis[i, 2]
+        qj = np.zeros(m.nv); vj = np.zeros(m.nv); aj = np.zeros(m.nv)
+        qj[ind] = qa; vj[ind] = va; aj[ind] = aa
+        r = evaluate(m, cfg, bodies, qj, vj, aj)
+        tau = np.array([r["tau"][body_of_joint[j]] for j in ind])
+        lam = L @ r["Froot"]
+        upd("tau", tau, ref["tau"][0, i]); upd("lambda", lam, ref["lam"][0, i])
+        # torso pose -> dependent q
+        gt = body_of_joint.get(6, None)
+        torso = [g for g in range(nb) if bodies[g]["link"] == 5][0]
+        qdep = np.concatenate([r["o"][torso], rpy_of(r["R"][torso])])
+        upd("q_dep", qdep, ref["q"][0, i, :6])
+        # Jacobian rows: expand with the basis
+        rows = [body_of_joint[j] for j in ind]
+        ptau = np.zeros((12, p.n)); plam = np.zeros((6, p.n))
+        for t, j in enumerate(ind):
+            k = body_of_joint[j]
+            for c in range(K):
+                w0, w1, w2 = basis[i, :, c]
+                ptau[:, t * K + c] = [r["Cq"][rr, k] * w0 + r["Cv"][rr, k] * w1 + r["Mt"][rr, k] * w2 for rr in rows]
+                plam[:, t * K + c] = L @ (r["FQ"][:, k] * w0 + r["FV"][:, k] * w1 + r["FA"][:, k] * w2)
+        upd("ptau_pz", ptau, ref["ptau_pz"][0, i]); upd("plambda_pz", plam, ref["plambda_pz"][0, i])
+    print(worst)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,3 +45,26 @@ def rel_err(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+
+
+def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None):
+    """Talos / Unitree-G1 single-step problem (TalosSingleStepOptimizer.cpp:17-124, G1 twin)."""
+    import os
+
+    from raptor_amd import robots
+
+    robots_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
+    if which == "talos":
+        m = robots.talos_model(os.path.join(robots_dir, "talos_reduced_armfixed_floatingbase.urdf"))
+        cfg = robots.talos_config(m, stance)
+    else:
+        m = robots.g1_model(os.path.join(robots_dir, "g1_22dof_floatingbase.urdf"))
+        cfg = robots.g1_config(m, stance)
+    if T_des is not None:
+        cfg.stance_foot_T_des_R, cfg.stance_foot_T_des_p = T_des
+    if degree is not None:
+        cfg.degree = degree
+    mh = api.model_create(m)
+    keep.append(mh)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV)
+    return A.ProblemHandle.legged(api, mh, t, cfg), m, cfg

@@ -202,3 +202,122 @@ def test_full_size_properties(hip, kinova):
     assert smooth.abs().max().item() < 1e-4
     obs = (num[:, p.block_offsets[3]:] - ana[:, p.block_offsets[3]:]).abs()
     assert (obs < 1e-4).double().mean().item() > 0.995  # kinks of the min / clamp are measure-zero but real
+
+
+# ---------------------------------------------------------------------------------------------------------
+# floating-base robots with a planted stance foot (Talos, Unitree-G1): ConstrainedInverseDynamics path
+# ---------------------------------------------------------------------------------------------------------
+def _rot(rpy):
+    from raptor_amd.urdf import rpy_to_matrix
+
+    return rpy_to_matrix(rpy)
+
+
+@pytest.mark.parametrize("which", ["talos", "g1"])
+@pytest.mark.parametrize("stance", ["L", "R"])
+def test_legged_constrained_inverse_dynamics(oracle, hip, which, stance):
+    """ConstrainedInverseDynamics::compute members (q, v, a, tau, lambda, ptau_pz, plambda_pz) per sample."""
+    N = 6
+    keep = []
+    po, m, cfg = H.legged_problem(oracle, which, keep, N=N, stance=stance)
+    ph, _, _ = H.legged_problem(hip, which, keep, N=N, stance=stance)
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    rng = np.random.default_rng(20250523 + 3)
+    Z = 0.3 * rng.uniform(-1, 1, (5, po.n))
+    ro = po.constrained_id_host(Z, N, m.nv, 12, 6)
+    rh = ph.constrained_id_host(Z, N, m.nv, 12, 6)
+    for key in ("q", "v", "a", "tau", "lam", "ptau_pz", "plambda_pz"):
+        check(rh[key], ro[key])
+    # the trailing v_reset / lambda_reset columns never enter (exact zeros on both sides)
+    assert np.all(rh["ptau_pz"][..., 84:] == 0) and np.all(ro["ptau_pz"][..., 84:] == 0)
+    rh2 = ph.constrained_id_host(Z, N, m.nv, 12, 6, derivatives=False)  # rnea-only instantiation
+    for key in ("q", "v", "a", "tau", "lam"):
+        check(rh2[key], ro[key])
+
+
+@pytest.mark.parametrize("which", ["talos", "g1"])
+def test_legged_eval_g_and_jac(oracle, hip, which):
+    """eval_g / eval_jac_g of the single-step problem: [torque limits | joint limits | contact], Optimizer order."""
+    keep = []
+    po, m, cfg = H.legged_problem(oracle, which, keep, N=14)
+    ph, _, _ = H.legged_problem(hip, which, keep, N=14)
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets) == (108, 14 * 37, [0, 168, 420, 518])
+    lo, uo = po.bounds()
+    lh, uh = ph.bounds()
+    assert np.array_equal(lo, lh) and np.array_equal(uo, uh)
+    rng = np.random.default_rng(20250523 + (2 if which == "talos" else 4))
+    Z = 0.1 * rng.uniform(-1, 1, (9, 108))  # TalosSingleStep.cpp:61 scale
+    Z[-1] *= 8.0                             # one far-from-nominal start
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    # structural zeros agree exactly: trailing v_reset / lambda_reset columns everywhere, and the independent-joint
+    # rows of the joint-limit block (one Bernstein block per row)
+    assert np.all(Jh[:, :, 84:] == 0.0) and np.all(Jo[:, :, 84:] == 0.0)
+    rows = np.array([168 + i * 18 + j for i in range(14) for j in cfg.independent_ids])
+    assert np.array_equal(Jh[:, rows] == 0.0, Jo[:, rows] == 0.0)
+    # elsewhere an exact zero on one side is at most rounding noise on the other
+    mism = (Jh == 0.0) != (Jo == 0.0)
+    assert np.abs(Jh[mism]).max(initial=0.0) < 1e-12 and np.abs(Jo[mism]).max(initial=0.0) < 1e-12, mism.sum()
+    Gh2, none = ph.eval_host(Z, A.EVAL_G)
+    assert none is None
+    check(Gh2, Gh, 1e-12)
+
+
+def test_legged_rotated_stance_foot_and_degree(oracle, hip):
+    """A desired stance-foot pose away from the identity (RPY rows of lambda go through A_des) and degree 5."""
+    T_des = (_rot([0.2, -0.3, 0.5]), [0.1, -0.2, 0.05])
+    keep = []
+    po, m, cfg = H.legged_problem(oracle, "talos", keep, N=5, T_des=T_des, degree=5)
+    ph, _, _ = H.legged_problem(hip, "talos", keep, N=5, T_des=T_des, degree=5)
+    rng = np.random.default_rng(11)
+    Z = 0.2 * rng.uniform(-1, 1, (3, po.n))
+    ro = po.constrained_id_host(Z, 5, m.nv, 12, 6)
+    rh = ph.constrained_id_host(Z, 5, m.nv, 12, 6)
+    for key in ("q", "v", "a", "tau", "lam", "ptau_pz", "plambda_pz"):
+        check(rh[key], ro[key])
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+
+
+def test_legged_full_size_properties(hip):
+    """BASELINE config 5 size on one GPU's shard (G1, 1024 problems x N = 14) through the device entry point."""
+    import torch
+
+    keep = []
+    p, m, cfg = H.legged_problem(hip, "g1", keep, N=14)
+    B = 1024
+    g = torch.Generator(device="cpu").manual_seed(20250527)
+    Z = (0.1 * (torch.rand(B, p.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
+    G = torch.empty(B, p.m, dtype=torch.float64, device="cuda")
+    J = torch.full((B, p.m, p.n), float("nan"), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    p.eval_device(Z.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G.data_ptr(), J.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(G).all() and torch.isfinite(J).all()  # every entry written
+    perm = torch.randperm(B, generator=g).cuda()
+    G2, J2 = torch.empty_like(G), torch.empty_like(J)
+    Zp = Z[perm].contiguous()
+    p.eval_device(Zp.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G2.data_ptr(), J2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(G2, G[perm]) and torch.equal(J2, J[perm])
+    d = torch.randn(B, p.n, generator=g, dtype=torch.float64).cuda()
+    h = 1e-6
+    G3 = torch.empty_like(G)
+    Zh, Zm = (Z + h * d).contiguous(), (Z - h * d).contiguous()
+    p.eval_device(Zh.data_ptr(), B, A.EVAL_G, G2.data_ptr(), 0, st)
+    p.eval_device(Zm.data_ptr(), B, A.EVAL_G, G3.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    num = (G2 - G3) / (2 * h)
+    ana = torch.einsum("bmn,bn->bm", J, d)
+    scale = 1 + ana.abs().max().item()
+    err = (num - ana).abs() / scale
+    kinked = torch.zeros(p.m, dtype=torch.bool, device="cuda")  # sqrt(fx^2 + fy^2) and |mz| rows (RectangleSurfaceContactConstraints.cpp:41-42)
+    for i in range(14):
+        kinked[p.block_offsets[2] + 7 * i + 1] = True
+        kinked[p.block_offsets[2] + 7 * i + 2] = True
+    assert err[:, ~kinked].max().item() < 1e-6
+    assert (err[:, kinked] < 1e-6).double().mean().item() > 0.99
