@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
-"""Headline benchmark: RNEA + d(tau)/dz sample-evals/s (fp64) on the Kinova batched configuration.
+"""Headline benchmark: RNEA + d(tau)/dz sample-evals/s (fp64).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload kinova|talos|g1]
   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A *step* is one pass of the hot path (eval_g + eval_jac_g, i.e. raptor_eval_batch with G|JAC) over one
-batch of B = 4096 decision vectors x N = 128 time samples = 524 288 sample-evals, inputs and outputs
-resident in HBM (BASELINE.json configs[1]).  With N GPUs every rank evaluates its own batch of 4096
-(multi-start problems are independent: weak scaling, no data-path collective).
+Default workload = BASELINE.json configs[1] (Kinova): a *step* is one pass of the hot path (eval_g + eval_jac_g, i.e.
+raptor_eval_batch with G|JAC) over one batch of B = 4096 decision vectors x N = 128 time samples = 524 288
+sample-evals, inputs and outputs resident in HBM.  With N GPUs every rank evaluates its own batch (multi-start
+problems are independent: weak scaling, no data-path collective).  `--workload talos|g1` runs the legged single-step
+problem (configs[2] / configs[4] shard: 1024 problems x 14 samples per GPU) the same way.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused Kinova evaluation kernel),
-timed live with HIP events recorded on the evaluation stream inside the timed region;
-`cpu_baseline` is the CPU oracle (a restatement of the reference: kind "port") timed on one host core
-over a bounded sample of the same batch.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events recorded on the
+evaluation stream inside the timed region; `cpu_baseline` is the CPU oracle (a restatement of the reference: kind
+"port") timed on one host core over a bounded sample of the same batch, which doubles as a last parity check.
 """
 from __future__ import annotations
 
@@ -29,14 +29,59 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
 
-N_SAMPLES = 128
-BATCH = 4096
-# algorithmic bytes per sample-eval = rows written once x (7 Jacobian columns + 1 value) x 8 B
-ROWS = 21 + 17  # JointLimits 7 + VelocityLimits 7 + TorqueLimits 7 rows + one row per collision sphere, per sample
-BYTES_ID = ROWS * 8 * 8   # 2432 B per sample-eval, the whole evaluation is one fused kernel
-# algorithmic flops per sample-eval: RNEA 550*nv + analytic derivatives ~7e3 + contraction 2058
-# + sphere FK / box distances ~25e3
-FLOPS_ID = 550 * 7 + 7000 + 2058 + 25000
+
+class Kinova:
+    """BASELINE configs[1]."""
+    name = "kinova"
+    samples = 128
+    batch = 4096
+    # algorithmic bytes per sample-eval = rows written once x (7 Jacobian columns + 1 value) x 8 B (SURVEY.md 8d)
+    rows = 21 + 17  # JointLimits 7 + VelocityLimits 7 + TorqueLimits 7 rows + one row per collision sphere
+    bytes_per_se = rows * 8 * 8
+    # algorithmic flops per sample-eval (SURVEY.md 8d): RNEA 550*nv + analytic derivatives ~7e3 + contraction 2058
+    # + sphere FK / box distances ~25e3
+    flops_per_se = 550 * 7 + 7000 + 2058 + 25000
+    dominant = 0  # index of the dominant kernel among the timed pair
+    kernels = ["kinova_fused_kernel<true> (trajectory + RNEA + d tau/dz + limit rows + sphere/box rows)", None]
+    pmc_key = "kinova_fused_kernel<true>"
+    z_scale = 1.0
+    workload = ("Kinova-gen3 7-DoF ArmourBezier, 128 Chebyshev samples x 4096 random z in U(-1,1)^7 per GPU, "
+                "eval_g+eval_jac_g (joint/velocity/torque limits + 17 spheres vs 10 boxes in reach), no solver")
+
+    def build(self, api, keep):
+        import helpers as H
+        import raptor_amd
+
+        model = raptor_amd.load_urdf(os.path.join(ROOT, "tests", "robots", "kinova.urdf"))
+        return H.kinova_problem(api, model, keep, N=self.samples, boxes=H.reach_boxes())
+
+
+class Legged:
+    """BASELINE configs[2] (Talos) / configs[4] (G1, one GPU's shard of the 8192-problem sweep)."""
+    samples = 14
+    batch = 1024
+    rows = 12 + 18 + 7
+    bytes_per_se = rows * 8 * (108 + 1)   # SURVEY.md 8d: 8 R (V + 1)
+    flops_per_se = 230000                 # SURVEY.md 8d total for Talos / G1 as the reference does it
+    dominant = 1
+    kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows)",
+               "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
+    pmc_key = "legged_expand_kernel"
+    z_scale = 0.1  # TalosSingleStep.cpp:61
+
+    def __init__(self, which):
+        self.name = which
+        self.workload = (f"{'Talos' if which == 'talos' else 'Unitree-G1'} single-step gait, nv=18 (6 floating + 12), Bezier degree 6, "
+                         f"14 Chebyshev samples x {self.batch} random z in 0.1*U(-1,1)^108 per GPU, eval_g+eval_jac_g "
+                         "(torque limits + constrained joint limits + rectangle contact), no solver")
+
+    def build(self, api, keep):
+        import helpers as H
+
+        return H.legged_problem(api, self.name, keep, N=self.samples)[0]
+
+
+WORKLOADS = {"kinova": Kinova, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1")}
 
 
 def main() -> None:
@@ -44,12 +89,12 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument("--workload", default="kinova", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
-    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,17 +112,15 @@ def main() -> None:
 
     import raptor_amd
     from raptor_amd import _capi as A
-    import helpers as H
 
+    W = WORKLOADS[args.workload]()
     hip = raptor_amd.api()  # raises if the HIP library is missing: there is no fallback
     hip.init(local_rank)
-    model = raptor_amd.load_urdf(os.path.join(ROOT, "tests", "robots", "kinova.urdf"))
     keep = []
-    boxes = H.reach_boxes()
-    prob = H.kinova_problem(hip, model, keep, N=N_SAMPLES, boxes=boxes)
-    B = args.batch
+    prob = W.build(hip, keep)
+    B = args.batch or W.batch
     gen = torch.Generator(device="cpu").manual_seed(20250523 + 1 + rank)
-    Z = (torch.rand(B, prob.n, generator=gen, dtype=torch.float64) * 2 - 1).cuda()
+    Z = (W.z_scale * (torch.rand(B, prob.n, generator=gen, dtype=torch.float64) * 2 - 1)).cuda()
     G = torch.empty(B, prob.m, dtype=torch.float64, device="cuda")
     J = torch.empty(B, prob.m, prob.n, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -100,20 +143,24 @@ def main() -> None:
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    n_prof, id_ms, obs_ms = prob.profile_end()
+    n_prof, k0_ms, k1_ms = prob.profile_end()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    sample_evals = B * N_SAMPLES
+    sample_evals = B * W.samples
     value = world * sample_evals * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
         assert bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all())
-        id_s = id_ms * 1e-3
+        kms = [k0_ms, k1_ms]
+        dom_ms = kms[W.dominant]
+        dom_s = dom_ms * 1e-3
+        tot_s = (k0_ms + k1_ms) * 1e-3
+        alg_bytes = sample_evals * W.bytes_per_se
         out = {
             "metric": "RNEA+dtau/dz sample-evals/sec (fp64)",
             "value": value,
@@ -128,63 +175,62 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "Kinova-gen3 7-DoF ArmourBezier, 128 Chebyshev samples x 4096 random z in U(-1,1)^7 per GPU, "
-                            "eval_g+eval_jac_g (joint/velocity/torque limits + 17 spheres vs 10 boxes in reach), no solver",
-                "batch_per_gpu": B, "samples": N_SAMPLES, "n": prob.n, "m": prob.m,
+                "workload": W.workload,
+                "batch_per_gpu": B, "samples": W.samples, "n": prob.n, "m": prob.m,
                 "flags": "G|JAC", "parallelism": f"multi-start x{world} (independent batches, no collective)",
             },
             "eval_jac_g_latency_ms_batch": ms_per_step,
             "roofline": {
-                "kernel": "kinova_fused_kernel<true> (trajectory + RNEA + d tau/dz + limit rows + sphere/box rows)",
+                "kernel": W.kernels[W.dominant],
                 "bound": "hbm",
-                "achieved": sample_evals * BYTES_ID / id_s / 1e9 if id_s > 0 else None,
+                "achieved": alg_bytes / dom_s / 1e9 if dom_s > 0 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": (sample_evals * BYTES_ID / id_s / 1e9) / HBM_PEAK_GBS if id_s > 0 else None,
-                "traffic": pmc_traffic(sample_evals * BYTES_ID),
-                "kernel_ms": id_ms,
+                "frac": (alg_bytes / dom_s / 1e9) / HBM_PEAK_GBS if dom_s > 0 else None,
+                "traffic": pmc_traffic(W.pmc_key),
+                "kernel_ms": dom_ms,
                 "launches_timed": n_prof,
-                "algorithmic_bytes_per_launch": sample_evals * BYTES_ID,
+                "algorithmic_bytes_per_launch": alg_bytes,
             },
             "roofline_fp64": {
-                "kernel": "kinova_fused_kernel<true>",
+                "kernel": "all kernels of one evaluation",
                 "bound": "fp64-valu",
-                "achieved": sample_evals * FLOPS_ID / id_s / 1e12 if id_s > 0 else None,
+                "achieved": sample_evals * W.flops_per_se / tot_s / 1e12 if tot_s > 0 else None,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": (sample_evals * FLOPS_ID / id_s / 1e12) / FP64_PEAK_TFLOPS if id_s > 0 else None,
-                "algorithmic_flops_per_sample_eval": FLOPS_ID,
+                "frac": (sample_evals * W.flops_per_se / tot_s / 1e12) / FP64_PEAK_TFLOPS if tot_s > 0 else None,
+                "algorithmic_flops_per_sample_eval": W.flops_per_se,
             },
+            "kernels_ms": {k: v for k, v in zip(W.kernels, kms) if k},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, boxes, Z.cpu().numpy(), args.cpu_seconds, G, J, prob)
+            out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), args.cpu_seconds, G, J)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(algorithmic_bytes):
+def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
-    collected with this same command in separate WRITE_SIZE / FETCH_SIZE runs); None when no such file is present."""
+    collected with this same command in separate WRITE_SIZE / FETCH_SIZE runs); None when no such entry is present."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        k = d["kinova_fused_kernel<true>"]
+        k = d[key]
         return k["WRITE_SIZE_bytes"] + k["FETCH_SIZE_bytes"]
     except Exception:
         return None
 
 
-def cpu_baseline(model, boxes, Zs, budget_s, G, J, prob):
+def cpu_baseline(W, Zs, budget_s, G, J):
     """The CPU oracle (restatement of the reference's serial per-sample loop), one host core, on the first few z
     of the same batch; also used as a last check of the GPU results on exactly those z."""
-    import numpy as np
     from raptor_amd import _capi as A
     import helpers as H
 
     oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
     keep = []
-    po = H.kinova_problem(oracle, model, keep, N=N_SAMPLES, boxes=boxes)
+    po = W.build(oracle, keep)
     t0 = time.perf_counter()
     po.eval_host(Zs[:1])
     per_z = time.perf_counter() - t0
@@ -197,13 +243,13 @@ def cpu_baseline(model, boxes, Zs, budget_s, G, J, prob):
     if not (eg < 1e-9 and ej < 1e-9):
         raise SystemExit(f"GPU result differs from the oracle: g {eg:.2e} pg_pz {ej:.2e}")
     return {
-        "value": nz * N_SAMPLES / dt,
+        "value": nz * W.samples / dt,
         "unit": "sample-evals/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {nz} of the 4096 z of the same batch (x128 samples), eval_g+eval_jac_g, oracle/liboracle.so "
-                  f"(-O2, serial like the reference's per-sample loop); GPU rows for those z checked against it: "
-                  f"rel err g {eg:.1e}, pg_pz {ej:.1e}",
+        "sample": f"first {nz} of the {len(Zs)} z of the same batch (x{W.samples} samples), eval_g+eval_jac_g, "
+                  f"oracle/liboracle.so (-O2, serial like the reference's per-sample loop); GPU rows for those z checked "
+                  f"against it: rel err g {eg:.1e}, pg_pz {ej:.1e}",
         "seconds": dt,
     }
 

@@ -320,8 +320,10 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st) {
+void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
+                   hipEvent_t between) {
     launch_legged_core(p, dZ, B, dG, jac, st);
+    if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
     const long long total = (long long)p.layout.m * p.layout.n;
     const int tiles = (int)((total / 2 + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK);
@@ -345,13 +347,13 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     if (p.kind == 1) {  // Kinova: one fused kernel
         if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
         else launch_kinova<false>(p, dZ, B, dG, nullptr, st);
-    } else if (p.kind == 2) {
-        launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st);
+    } else if (p.kind == 2) {  // legged: core kernel, then the streaming expansion (timed separately)
+        launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st, prof ? p.ev[p.ev_used + 1] : nullptr);
     } else {
         if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
         else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
     }
-    if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+    if (prof && p.kind != 2) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
     if (prof) {
         HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
         p.ev_used += 3;
