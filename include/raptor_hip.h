@@ -122,6 +122,30 @@ typedef struct raptor_legged_desc {
     double mu, gamma, Lx, Ly;       /* rectangleContactSurfaceParams(MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH)           */
 } raptor_legged_desc;
 
+/*
+ * Digit-v3 single-step problem: the arguments of DigitSingleStepOptimizer::set_parameters that reach the hot path
+ * (Examples/Digit/src/DigitSingleStepOptimizer.cpp:17-124) plus the joint ids DigitDynamicsConstraints looks up by name
+ * (Examples/Digit/include/DigitDynamicsConstraints.h:19-57).  The closed-loop constants (rod / anchor end points,
+ * stance-foot end transform, initial-guess fit) are compiled in, as the reference hard-codes them
+ * (DigitDynamicsConstraints.h:178-198, DigitDynamicsConstraints.cpp:255-314).
+ * Blocks built: [torque limits N*12 | joint limits N*36 | contact N*7].
+ */
+typedef struct raptor_digit_desc {
+    raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = 12                                               */
+    int extra_variables;            /* NUM_JOINTS + NUM_DEPENDENT_JOINTS appended to varLength                    */
+    int base_ids[6];                /* model.getJointId(name) - 1 of Px, Py, Pz, Rx, Ry, Rz                        */
+    int leg_ids[2][15];             /* [0] left, [1] right: hip_roll, hip_yaw, hip_pitch, achilles_rod, ach2, knee,
+                                       tarsus, toe_A, toe_A_rod, A2, toe_B, toe_B_rod, B2, toe_pitch, toe_roll     */
+    int stance_leg;                 /* 'L' or 'R'                                                                  */
+    double stance_foot_T_des_R[9];  /* row-major; default Transform(3, -pi/2) (DigitSingleStepOptimizer.h:50)      */
+    double stance_foot_T_des_p[3];
+    const double* torque_limits_lower; /* [12] */
+    const double* torque_limits_upper;
+    const double* joint_limits_lower;  /* [36] radians */
+    const double* joint_limits_upper;
+    double mu, gamma, Lx, Ly;
+} raptor_digit_desc;
+
 typedef struct raptor_model raptor_model;     /* opaque */
 typedef struct raptor_problem raptor_problem; /* opaque */
 
@@ -149,9 +173,14 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
  * (KinematicsDynamics/src/ConstrainedInverseDynamics.cpp:45-184, DynamicsConstraints.cpp:36-103). */
 int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_desc* desc, raptor_problem** out);
 
+/* DigitSingleStepOptimizer::set_parameters: DigitConstrainedInverseDynamics (closed-loop DigitDynamicsConstraints,
+ * Examples/Digit/src/DigitDynamicsConstraints.cpp:242-400) + the three blocks above. */
+int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_desc* desc, raptor_problem** out);
+
 /* ConstrainedInverseDynamics::compute results per sample, host buffers (ConstrainedInverseDynamics.h:44-56); any may be NULL:
- *   q, v, a [B][N][nv] (dependent joints filled in), tau [B][N][Nact], lambda [B][N][n_dep],
- *   ptau_pz [B][N][Nact][n], plambda_pz [B][N][n_dep][n]  (row-major) */
+ *   q, v, a [B][N][nv] (dependent joints filled in), tau [B][N][Nact], lambda [B][N][6] = lambda.tail(6),
+ *   the stance-foot contact wrench (the rows RectangleSurfaceContactConstraints reads),
+ *   ptau_pz [B][N][Nact][n], plambda_pz [B][N][6][n]  (row-major) */
 int raptor_constrained_id_eval_host(raptor_problem* problem, const double* Z, int B, double* q, double* v, double* a,
                                     double* tau, double* lambda, double* ptau_pz, double* plambda_pz);
 

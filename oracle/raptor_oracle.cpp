@@ -966,6 +966,8 @@ struct KinovaCustomizedConstraints : Constraints {
     }
 };
 
+#include "../raptor_amd/csrc/digit_constants.h"
+#include "../raptor_amd/csrc/digit_tables.h"
 #include "legged_oracle.inc"
 
 // ------------------------------------------------------------------ problem = Optimizer's constraint list
@@ -1321,6 +1323,108 @@ int oracle_legged_problem_create(const raptor_model* model, const raptor_legged_
     ORACLE_CATCH
 }
 
+int oracle_digit_problem_create(const raptor_model* model, const raptor_digit_desc* d, raptor_problem** out) {
+    ORACLE_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    std::unique_ptr<raptor_problem> pr(new raptor_problem());
+    Problem& p = pr->p;
+    p.model = model->m;
+    const int nv = p.model.nv;
+    if (nv != 36) throw std::invalid_argument("Digit: NUM_JOINTS is 36");
+    if (d->traj.type != RAPTOR_TRAJ_BEZIER) throw std::invalid_argument("single-step optimizers use BezierCurves");
+    p.traj.init(&d->traj);
+    if (p.traj.Nact != 12) throw std::invalid_argument("Digit: NUM_INDEPENDENT_JOINTS is 12");
+    if (d->extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
+    p.traj.varLength += d->extra_variables;  // DigitSingleStepOptimizer.cpp:50-51
+    p.traj.pq_pz.assign(p.traj.N, MatX(p.traj.Nact, p.traj.varLength));
+    p.traj.pq_d_pz = p.traj.pq_pz;
+    p.traj.pq_dd_pz = p.traj.pq_pz;
+    if (d->stance_leg != 'L' && d->stance_leg != 'R' && d->stance_leg != 'l' && d->stance_leg != 'r')
+        throw std::runtime_error("Invalid stance leg input");
+    const int sleg = (d->stance_leg == 'L' || d->stance_leg == 'l') ? 0 : 1;
+    ContactDynamicsConstraints& dc = p.dc;
+    dc.model = &p.model;
+    dc.fk.model = &p.model;
+    dc.nv = nv;
+    dc.nd = 24;
+    dc.ni = 12;
+    std::vector<int> seen(nv, 0);
+    auto take = [&](int id) {
+        if (id < 0 || id >= nv || seen[id]++) throw std::runtime_error("Can not find joint");
+        return id;
+    };
+    for (int k = 0; k < 6; k++) dc.dep.push_back(take(d->base_ids[k]));  // DigitDynamicsConstraints.h:19-57 order
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 9; k++) dc.dep.push_back(take(d->leg_ids[leg][DIGIT_LEG_DEPENDENT[k]]));
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 6; k++) dc.ind.push_back(take(d->leg_ids[leg][DIGIT_LEG_INDEPENDENT[k]]));
+    dc.fk_start = d->base_ids[5] + 1;
+    dc.contact_joint_id = d->leg_ids[sleg][DG_TOE_ROLL] + 1;
+    {
+        double R[9], pp[3];
+        digit_stance_foot_endT(sleg, R, pp);
+        Mat3 Re;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Re(r, c) = R[3 * r + c];
+        dc.stance_foot_endT = Transform(Re, Vec3(pp[0], pp[1], pp[2]));
+    }
+    Mat3 Rd;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Rd(r, c) = d->stance_foot_T_des_R[3 * r + c];
+    dc.stance_foot_T_des = Transform(Rd, Vec3(d->stance_foot_T_des_p[0], d->stance_foot_T_des_p[1], d->stance_foot_T_des_p[2]));
+    // closures in the row order of the compiled reference file (DigitDynamicsConstraints.cpp:579-596):
+    // right toe-A, right toe-B, left toe-A, left toe-B, right knee, left knee
+    const int order[6][2] = {{1, 0}, {1, 1}, {0, 0}, {0, 1}, {1, 2}, {0, 2}};
+    for (int k = 0; k < 6; k++) {
+        const int leg = order[k][0];
+        const DigitLoop& L = DIGIT_LOOPS[order[k][1]];
+        Closure cl;
+        cl.start = d->leg_ids[leg][L.start] + 1;
+        cl.endA = d->leg_ids[leg][L.endA] + 1;
+        cl.endB = d->leg_ids[leg][L.endB] + 1;
+        cl.endTA = Transform(Vec3(L.rod[0], L.rod[1], L.rod[2]));
+        double an[3] = {L.anchor[leg][0], L.anchor[leg][1], L.anchor[leg][2]};
+        if (order[k][1] == 2) digit_knee_anchor(leg, an);
+        cl.endTB = Transform(Vec3(an[0], an[1], an[2]));
+        dc.closures.push_back(cl);
+    }
+    for (int leg = 0; leg < 2; leg++) {
+        for (int k = 0; k < 6; k++) {
+            const DigitToeGuess& g = DIGIT_TOE_GUESS[leg][k];
+            LoopGuess lg;
+            lg.nin = 2;
+            lg.in_joint[0] = d->leg_ids[leg][DG_TOE_A];
+            lg.in_joint[1] = d->leg_ids[leg][DG_TOE_B];
+            lg.out_joint = d->leg_ids[leg][DIGIT_LOOPS[0].depj[k]];
+            lg.sign = g.sign; lg.c0 = g.c0;
+            lg.lin.assign(g.lin, g.lin + 8);
+            lg.pair.assign(g.pair, g.pair + DIGIT_TOE_NPAIR);
+            dc.guesses.push_back(lg);
+        }
+        for (int k = 0; k < 3; k++) {
+            const DigitKneeGuess& g = DIGIT_KNEE_GUESS[leg][k];
+            LoopGuess lg;
+            lg.nin = 1;
+            lg.in_joint[0] = d->leg_ids[leg][DG_KNEE];
+            lg.out_joint = d->leg_ids[leg][DIGIT_LOOPS[2].depj[k]];
+            lg.sign = g.sign; lg.c0 = g.c0;
+            lg.lin.assign(g.lin, g.lin + 4);
+            dc.guesses.push_back(lg);
+        }
+    }
+    p.cid.model = &p.model;
+    p.cid.traj = &p.traj;
+    p.cid.dc = &p.dc;
+    VecX tl(d->torque_limits_lower, d->torque_limits_lower + 12), tu(d->torque_limits_upper, d->torque_limits_upper + 12);
+    VecX jl(d->joint_limits_lower, d->joint_limits_lower + nv), ju(d->joint_limits_upper, d->joint_limits_upper + nv);
+    p.cons.emplace_back(new ConstrainedTorqueLimits(&p.cid, tl, tu));                                   // DigitSingleStepOptimizer.cpp:74-79
+    p.cons.emplace_back(new ConstrainedJointLimits(&p.cid, jl, ju));                                    // :82-87
+    p.cons.emplace_back(new RectangleSurfaceContactConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly)); // :90-94
+    p.finish();
+    *out = pr.release();
+    ORACLE_CATCH
+}
+
 int oracle_constrained_id_eval_host(raptor_problem* pr, const double* Z, int B, double* q, double* v, double* a,
                                     double* tau, double* lambda, double* ptau_pz, double* plambda_pz) {
     ORACLE_TRY
@@ -1343,10 +1447,10 @@ int oracle_constrained_id_eval_host(raptor_problem* pr, const double* Z, int B, 
                 if (ptau_pz)
                     for (int c = 0; c < n; c++) ptau_pz[(e * ni + j) * n + c] = p.cid.ptau_pz[i](j, c);
             }
-            for (int j = 0; j < nd; j++) {
-                if (lambda) lambda[e * nd + j] = p.cid.lambda[i][j];
+            for (int j = 0; j < 6; j++) {  // lambda.tail(6): the stance-foot contact wrench
+                if (lambda) lambda[e * 6 + j] = p.cid.lambda[i][nd - 6 + j];
                 if (plambda_pz)
-                    for (int c = 0; c < n; c++) plambda_pz[(e * nd + j) * n + c] = p.cid.plambda_pz[i](j, c);
+                    for (int c = 0; c < n; c++) plambda_pz[(e * 6 + j) * n + c] = p.cid.plambda_pz[i](nd - 6 + j, c);
             }
         }
     }

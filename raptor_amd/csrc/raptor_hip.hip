@@ -691,6 +691,13 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
     API_CATCH
 }
 
+int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_desc* d, raptor_problem** out) {
+    API_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    throw unsupported_error("Digit closed-loop kernel: not built yet");
+    API_CATCH
+}
+
 int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, double* q, double* v, double* a,
                                     double* tau, double* lambda, double* ptau_pz, double* plambda_pz) {
     API_TRY

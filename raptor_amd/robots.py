@@ -116,3 +116,75 @@ def g1_config(m: RobotModel, stance_leg: str = "L") -> LeggedConfig:
         joint_limits_lower=np.array(lo, dtype=float), joint_limits_upper=np.array(up, dtype=float),
         mu=0.7, gamma=0.7, Lx=0.10, Ly=0.03,
     )
+
+
+# ---- Digit-v3: Examples/Digit/include/DigitConstants.h, DigitDynamicsConstraints.h:19-57, DigitSingleStep.cpp:16-40 ----
+DIGIT_LEG_JOINTS = ["hip_roll", "hip_yaw", "hip_pitch", "achilles_rod", "ach2", "knee", "tarsus", "toe_A", "toe_A_rod",
+                    "A2", "toe_B", "toe_B_rod", "B2", "toe_pitch", "toe_roll"]
+_DIGIT_ARMATURE = {"hip_roll": 0.173823936, "hip_yaw": 0.067899975, "hip_pitch": 0.1204731904, "knee": 0.1204731904,
+                   "toe_A": 0.036089475, "toe_B": 0.036089475}
+# degrees (DigitConstants.h:13-91)
+_DIGIT_JL_LO = [-1000] * 6 + [-60, -40, -60, -180, -10, -16.5480 - 15, -50.3, -26.8765 - 15, -180, -10, -1.1295 - 15, -180, -10, -44, -37,
+                              -60, -40, -90, -180, -10, -58.4, -71.6, -18.2531 - 15, -180, -10, -26.2724 - 15, -180, -10, -34, -33]
+_DIGIT_JL_UP = [1000] * 6 + [60, 40, 90, 180, 10, 58.4, 71.6, 0.4032 + 15, 180, 10, 26.2183 + 15, 180, 10, 34, 33,
+                             60, 40, 60, 180, 10, 30.7455 + 15, 50.3, 27.0323 + 15, 180, 10, 14.6109 + 15, 180, 10, 44, 37]
+_DIGIT_TL_LO = [-113.000, -79.1765, -216.928, -231.317, -41.9759, -41.9759, -126.682, -79.1765, -216.928, -231.317, -41.9759, -41.9759]
+_DIGIT_TL_UP = [113.000, 79.1765, 216.928, 231.317, 41.9759, 41.9759, 126.682, 79.1765, 216.928, 231.317, 41.9759, 41.9759]
+
+
+@dataclasses.dataclass
+class DigitConfig:
+    base_ids: List[int]
+    leg_ids: List[List[int]]
+    stance_leg: str
+    extra_variables: int
+    stance_foot_T_des_R: np.ndarray
+    stance_foot_T_des_p: Sequence[float]
+    torque_limits_lower: np.ndarray
+    torque_limits_upper: np.ndarray
+    joint_limits_lower: np.ndarray
+    joint_limits_upper: np.ndarray
+    mu: float = 0.7
+    gamma: float = 0.7
+    Lx: float = 0.04     # FOOT_WIDTH
+    Ly: float = 0.1175   # FOOT_LENGTH
+    degree: int = 5
+    T: float = 0.4
+    N: int = 14
+
+    @property
+    def independent_ids(self):
+        return [self.leg_ids[leg][DIGIT_LEG_JOINTS.index(n)] for leg in range(2)
+                for n in ("hip_roll", "hip_yaw", "hip_pitch", "knee", "toe_A", "toe_B")]
+
+    @property
+    def dependent_ids(self):
+        return list(self.base_ids) + [self.leg_ids[leg][DIGIT_LEG_JOINTS.index(n)] for leg in range(2)
+                                      for n in ("achilles_rod", "ach2", "tarsus", "toe_A_rod", "A2", "toe_B_rod", "B2",
+                                                "toe_pitch", "toe_roll")]
+
+
+def digit_model(urdf_path: str) -> RobotModel:
+    """DigitSingleStep.cpp:16-40: gravity -9.806, friction zeroed, motor inertias on the twelve actuated joints."""
+    m = load_urdf(urdf_path)
+    m.gravity = np.array([0.0, 0.0, -9.806])
+    m.friction[:] = 0
+    for side in ("left", "right"):
+        for n, val in _DIGIT_ARMATURE.items():
+            m.armature[m.joint_id(f"{side}_{n}")] = val
+    return m
+
+
+def digit_config(m: RobotModel, stance_leg: str = "L") -> DigitConfig:
+    c, s = np.cos(-np.pi / 2), np.sin(-np.pi / 2)
+    Rdes = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])  # Transform(3, -M_PI_2), DigitSingleStepOptimizer.h:50
+    return DigitConfig(
+        base_ids=[m.joint_id(n) for n in ("Px", "Py", "Pz", "Rx", "Ry", "Rz")],
+        leg_ids=[[m.joint_id(f"{side}_{n}") for n in DIGIT_LEG_JOINTS] for side in ("left", "right")],
+        stance_leg=stance_leg,
+        extra_variables=36 + 24,  # DigitSingleStepOptimizer.cpp:50-51
+        stance_foot_T_des_R=Rdes, stance_foot_T_des_p=[0.0, 0.0, 0.0],
+        torque_limits_lower=np.array(_DIGIT_TL_LO), torque_limits_upper=np.array(_DIGIT_TL_UP),
+        joint_limits_lower=np.deg2rad(np.array(_DIGIT_JL_LO, dtype=float)),
+        joint_limits_upper=np.deg2rad(np.array(_DIGIT_JL_UP, dtype=float)),
+    )

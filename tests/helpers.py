@@ -68,3 +68,22 @@ def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None):
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV)
     return A.ProblemHandle.legged(api, mh, t, cfg), m, cfg
+
+
+def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None):
+    """Digit-v3 single-step problem (DigitSingleStepOptimizer.cpp:17-124)."""
+    import os
+
+    from raptor_amd import robots
+
+    robots_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
+    m = robots.digit_model(os.path.join(robots_dir, "digit-v3-armfixedspecific-floatingbase-springfixed.urdf"))
+    cfg = robots.digit_config(m, stance)
+    if T_des is not None:
+        cfg.stance_foot_T_des_R, cfg.stance_foot_T_des_p = T_des
+    if degree is not None:
+        cfg.degree = degree
+    mh = api.model_create(m)
+    keep.append(mh)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV)
+    return A.ProblemHandle.digit(api, mh, t, cfg), m, cfg
