@@ -1,0 +1,268 @@
+"""numpy model of the Digit path of the legged HIP kernels, checked against the oracle.
+
+  loops   : each closed loop is solved in its own local frame (knee loop: 3 unknowns / 1 driver, toe loops: 6 unknowns /
+            2 drivers); Y1 = d dep/d drv, Y2, Y3 by implicit differentiation of c(y(x), x) = 0 with the chain identities
+            d^2 p/dth_i dth_j = w_i x (w_j x r_j) (i <= j),  d^3 p = w_i x (w_j x (w_k x r_k)) (i <= j <= k)
+  dynamics: fixed-base tree rooted at the stance toe_roll link over ALL 30 leg joints (proto_rerooted.evaluate),
+            theta = Phi(q_i), theta' = G q_i', theta'' = G q_i'' + g2;  tau = G^T tau_tree,
+            d tau/d(q,v,a)_i by the column weights (G, Hv/2, Hq), (0, G, Hv), (0, 0, G) and the (dG^T/dq) tau_tree term.
+Run: python scripts/proto_digit.py"""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H
+from raptor_amd import _capi as A
+from raptor_amd.robots import DIGIT_LEG_JOINTS as LJ
+from raptor_amd.urdf import jtype_transform
+from proto_world_derivs import crf, crm, skew
+from proto_legged import rpy_rate_matrix
+import proto_rerooted as PR
+
+R_ = {n: i for i, n in enumerate(LJ)}
+
+
+def knee_anchor(leg):
+    sg = 1.0 if leg == 0 else -1.0
+    r, p, y = np.deg2rad([sg * 4.47, 0.32, sg * 155.8])
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    return np.array([-0.01766, -sg * 0.029456, 0.00104]) + Rx @ Ry @ Rz @ np.array([0.113789, -sg * 0.011056, 0.0])
+
+
+def loops_of_leg(cfg, leg):
+    """[(drivers, deps, [(chainA, endA, chainB, endB), ...])] in model joint indices."""
+    ids = cfg.leg_ids[leg]
+    sg = -1.0 if leg == 0 else 1.0
+    J = lambda n: ids[R_[n]]
+    toe = ([J("toe_A"), J("toe_B")],
+           [J("toe_A_rod"), J("A2"), J("toe_B_rod"), J("B2"), J("toe_pitch"), J("toe_roll")],
+           [([J("toe_A"), J("toe_A_rod"), J("A2")], np.array([0.34, 0, 0]), [J("toe_pitch"), J("toe_roll")], np.array([0.0179, sg * 0.009551, -0.054164])),
+            ([J("toe_B"), J("toe_B_rod"), J("B2")], np.array([0.288, 0, 0]), [J("toe_pitch"), J("toe_roll")], np.array([-0.0181, sg * 0.009551, -0.054164]))])
+    knee = ([J("knee")], [J("achilles_rod"), J("ach2"), J("tarsus")],
+            [([J("achilles_rod"), J("ach2")], np.array([0.5, 0, 0]), [J("knee"), J("tarsus")], knee_anchor(leg))])
+    return [knee, toe]
+
+
+def chain_geometry(m, chain, th, end):
+    """local-frame axes w_j, origins o_j and end point p of a serial chain."""
+    Rw = np.eye(3); ow = np.zeros(3); ws = []; os_ = []
+    for j in chain:
+        Aw = Rw @ m.placement_R[j]; oj = ow + Rw @ m.placement_p[j]
+        jt = int(m.jtype[j]); aj = abs(jt); sg = 1.0 if jt > 0 else -1.0
+        assert aj <= 3
+        ws.append(sg * Aw[:, aj - 1]); os_.append(oj)
+        Rq, _ = jtype_transform(jt, th[j])
+        Rw = Aw @ Rq; ow = oj
+    return ws, os_, ow + Rw @ end
+
+
+def point_derivs(ws, os_, p, us):
+    """D^k p[u1..uk] for k = len(us) in 1..3 (us: per-chain-joint direction arrays)."""
+    n = len(ws)
+    out = np.zeros(3)
+    k = len(us)
+    for idx in itertools.product(range(n), repeat=k):
+        srt = sorted(idx)
+        coef = 1.0
+        for u, i in zip(us, idx):
+            coef *= u[i]
+        if coef == 0.0:
+            continue
+        v = np.cross(ws[srt[-1]], p - os_[srt[-1]])
+        for i in reversed(srt[:-1]):
+            v = np.cross(ws[i], v)
+        out += coef * v
+    return out
+
+
+class Loop:
+    def __init__(self, m, drivers, deps, closures):
+        self.m, self.drv, self.dep, self.cl = m, drivers, deps, closures
+        self.joints = deps + drivers  # local variable order: y then x
+
+    def c_and_geo(self, th):
+        c = []; geo = []
+        for (chA, eA, chB, eB) in self.cl:
+            wa, oa, pa = chain_geometry(self.m, chA, th, eA)
+            wb, ob, pb = chain_geometry(self.m, chB, th, eB)
+            c.append(pa - pb); geo.append((chA, wa, oa, pa, chB, wb, ob, pb))
+        return np.concatenate(c), geo
+
+    def D(self, geo, dirs):
+        """D^k c[dirs...] ; dirs: list of dicts joint -> value"""
+        out = []
+        for (chA, wa, oa, pa, chB, wb, ob, pb) in geo:
+            ua = [np.array([d.get(j, 0.0) for j in chA]) for d in dirs]
+            ub = [np.array([d.get(j, 0.0) for j in chB]) for d in dirs]
+            out.append(point_derivs(wa, oa, pa, ua) - point_derivs(wb, ob, pb, ub))
+        return np.concatenate(out)
+
+    def solve(self, th):
+        for it in range(50):
+            c, geo = self.c_and_geo(th)
+            Jy = np.column_stack([self.D(geo, [{j: 1.0}]) for j in self.dep])
+            if np.abs(c).sum() < 1e-15 and it > 0:
+                break
+            dy = np.linalg.solve(Jy, c)
+            for j, d in zip(self.dep, dy):
+                th[j] -= d
+        c, geo = self.c_and_geo(th)
+        Jy = np.column_stack([self.D(geo, [{j: 1.0}]) for j in self.dep])
+        nx, ny = len(self.drv), len(self.dep)
+        Y1 = np.zeros((ny, nx))
+        U = []
+        for a in range(nx):
+            Y1[:, a] = -np.linalg.solve(Jy, self.D(geo, [{self.drv[a]: 1.0}]))
+            u = {self.drv[a]: 1.0}
+            u.update({j: Y1[r, a] for r, j in enumerate(self.dep)})
+            U.append(u)
+        Y2 = np.zeros((ny, nx, nx)); U2 = {}
+        for a in range(nx):
+            for b in range(nx):
+                Y2[:, a, b] = -np.linalg.solve(Jy, self.D(geo, [U[a], U[b]]))
+                U2[a, b] = {j: Y2[r, a, b] for r, j in enumerate(self.dep)}
+        Y3 = np.zeros((ny, nx, nx, nx))
+        for a in range(nx):
+            for b in range(nx):
+                for d in range(nx):
+                    rhs = (self.D(geo, [U[a], U[b], U[d]]) + self.D(geo, [U2[a, b], U[d]]) + self.D(geo, [U2[a, d], U[b]])
+                           + self.D(geo, [U2[b, d], U[a]]))
+                    Y3[:, a, b, d] = -np.linalg.solve(Jy, rhs)
+        return Y1, Y2, Y3, it
+
+
+def main():
+    oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
+    N = 4
+    keep = []
+    stance = sys.argv[1] if len(sys.argv) > 1 else "L"
+    p, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance)
+    sleg = 0 if stance == "L" else 1
+    nv = m.nv
+    rng = np.random.default_rng(5)
+    Z = 0.1 * rng.uniform(-1, 1, (1, p.n))
+    ref = p.constrained_id_host(Z, N, nv, 12, derivatives=True)
+    Gref, Jref = p.eval_host(Z)
+    K = cfg.degree + 1
+    basis = np.zeros((N, 3, K))
+    for k in range(K):
+        zz = np.zeros((1, p.n)); zz[0, k] = 1.0
+        qq, qd, qdd = p.trajectory_host(zz, N, 12)
+        basis[:, 0, k] = qq[0, :, 0]; basis[:, 1, k] = qd[0, :, 0]; basis[:, 2, k] = qdd[0, :, 0]
+    ind = cfg.independent_ids
+    dep_all = cfg.dependent_ids
+    foot = cfg.leg_ids[sleg][R_["toe_roll"]]
+    bodies = PR.reroot(m, foot)
+    nb = len(bodies)
+    print("bodies", nb, "max depth", max(len(_path(bodies, g)) for g in range(nb)))
+    body_of_joint = {bodies[g]["joint"]: g for g in range(1, nb)}
+    torso = [g for g in range(nb) if bodies[g]["link"] == 5][0]
+    # root pose: T_des * endT^-1
+    s3 = np.sin(np.pi / 3)
+    Re = np.array([[0, 1, 0], [-0.5, 0, s3], [s3, 0, 0.5]]) if sleg == 0 else np.array([[0, -1, 0], [0.5, 0, -s3], [s3, 0, 0.5]])
+    pe = np.array([0, -0.05456, -0.0315]) if sleg == 0 else np.array([0, 0.05456, -0.0315])
+    Rd = np.asarray(cfg.stance_foot_T_des_R, float); pd = np.asarray(cfg.stance_foot_T_des_p, float)
+    R0 = Rd @ Re.T; o0 = pd - R0 @ pe
+
+    class Cfg2:  # what PR.evaluate reads
+        stance_foot_T_des_R = R0; stance_foot_T_des_p = o0; stance_foot_endT_p = np.zeros(3)
+    Ades = np.linalg.inv(rpy_rate_matrix(Rd))
+    Xp = np.eye(6); Xp[:3, 3:] = -skew(pd)
+    W6 = np.zeros((6, 6)); W6[:3, 3:] = np.eye(3); W6[3:, :3] = Ades.T
+    Lmap = W6 @ Xp
+    loops = [Loop(m, *l) for leg in range(2) for l in loops_of_leg(cfg, leg)]
+    worst = {}
+
+    def upd(k, x, y):
+        worst[k] = max(worst.get(k, 0), float(np.abs(np.asarray(x) - np.asarray(y)).max() / (1 + np.abs(y).max())))
+    for i in range(N):
+        coef = Z[0, :12 * K].reshape(12, K)
+        qa = coef @ basis[i, 0]; va = coef @ basis[i, 1]; aa = coef @ basis[i, 2]
+        th = np.zeros(nv); thd = np.zeros(nv); thdd = np.zeros(nv)
+        th[ind] = qa; thd[ind] = va; thdd[ind] = aa
+        ti = {j: t for t, j in enumerate(ind)}
+        # weights per tree joint: list of (minimal col, G, Hv, Hq);  Y2 kept for the dG^T tau term
+        Wt = {j: [(ti[j], 1.0, 0.0, 0.0)] for j in ind}
+        y2s = []
+        for lp in loops:
+            for j in lp.dep:  # crude start (the kernel uses the fitted guess): oracle value + noise
+                th[j] = ref["q"][0, i, j] + 0.02 * rng.uniform(-1, 1)
+            Y1, Y2, Y3, its = lp.solve(th)
+            xd = np.array([thd[j] for j in lp.drv]); xdd = np.array([thdd[j] for j in lp.drv])
+            for r, j in enumerate(lp.dep):
+                thd[j] = Y1[r] @ xd
+                thdd[j] = Y1[r] @ xdd + xd @ Y2[r] @ xd
+                Wt[j] = [(ti[lp.drv[a]], Y1[r, a], 2 * Y2[r, a] @ xd, Y2[r, a] @ xdd + xd @ Y3[r, a] @ xd) for a in range(len(lp.drv))]
+            y2s.append((lp, Y2))
+        upd("q_loop", th[6:], ref["q"][0, i, 6:]); upd("v_loop", thd[6:], ref["v"][0, i, 6:]); upd("a_loop", thdd[6:], ref["a"][0, i, 6:])
+        r = PR.evaluate(m, Cfg2, bodies, th, thd, thdd)
+        tt = r["tau"]  # per body
+        # T = X * Y, then R = G^T T
+        T = np.zeros((3, nb, 12)); TF = np.zeros((3, 6, 12))
+        for j, lst in Wt.items():
+            k = body_of_joint[j]
+            for (col, g0, hv, hq) in lst:
+                T[2, :, col] += r["Mt"][:, k] * g0
+                T[1, :, col] += r["Cv"][:, k] * g0 + r["Mt"][:, k] * hv
+                T[0, :, col] += r["Cq"][:, k] * g0 + r["Cv"][:, k] * hv / 2 + r["Mt"][:, k] * hq
+                TF[2, :, col] += r["FA"][:, k] * g0
+                TF[1, :, col] += r["FV"][:, k] * g0 + r["FA"][:, k] * hv
+                TF[0, :, col] += r["FQ"][:, k] * g0 + r["FV"][:, k] * hv / 2 + r["FA"][:, k] * hq
+        Rm = np.zeros((3, 12, 12)); tau = np.zeros(12)
+        for j, lst in Wt.items():
+            k = body_of_joint[j]
+            for (col, g0, hv, hq) in lst:
+                Rm[:, col, :] += g0 * T[:, k, :]
+                tau[col] += g0 * tt[k]
+        for lp, Y2 in y2s:  # (dG^T/dq) tau_tree
+            for rr, j in enumerate(lp.dep):
+                for a in range(len(lp.drv)):
+                    for b in range(len(lp.drv)):
+                        Rm[0, ti[lp.drv[a]], ti[lp.drv[b]]] += Y2[rr, a, b] * tt[body_of_joint[j]]
+        lam = Lmap @ r["Froot"]
+        upd("tau", tau, ref["tau"][0, i]); upd("lambda", lam, ref["lam"][0, i])
+        qdep = np.concatenate([r["o"][torso], PR.rpy_of(r["R"][torso])])
+        upd("q_base", qdep, ref["q"][0, i, :6])
+        ptau = np.zeros((12, p.n)); plam = np.zeros((6, p.n))
+        for t in range(12):
+            for c in range(K):
+                w0, w1, w2 = basis[i, :, c]
+                ptau[:, t * K + c] = Rm[0, :, t] * w0 + Rm[1, :, t] * w1 + Rm[2, :, t] * w2
+                plam[:, t * K + c] = Lmap @ (TF[0, :, t] * w0 + TF[1, :, t] * w1 + TF[2, :, t] * w2)
+        upd("ptau_pz", ptau, ref["ptau_pz"][0, i]); upd("plambda_pz", plam, ref["plambda_pz"][0, i])
+        # P_dep: base rows from the torso twist, loop rows = Y1
+        P = np.zeros((nv, 12))
+        ot = r["o"][torso]; Wm = rpy_rate_matrix(r["R"][torso])
+        for j, lst in Wt.items():
+            k = body_of_joint[j]
+            on_path = k <= torso < bodies[k]["end"]
+            for (col, g0, hv, hq) in lst:
+                if j not in ind:
+                    P[j, col] += g0
+                if on_path:
+                    s = r["s"][k]
+                    P[0:3, col] += g0 * (s[3:] + np.cross(s[:3], ot)); P[3:6, col] += g0 * (Wm @ s[:3])
+        off = p.block_offsets[1]
+        for jj in dep_all:
+            row = Jref[0, off + i * nv + jj].reshape(-1)[:12 * K].reshape(12, K)
+            upd("P_dep", P[jj] * basis[i, 0, 2], row[:, 2])
+    print(worst)
+
+
+def _path(bodies, g):
+    out = []
+    while g > 0:
+        out.append(g); g = bodies[g]["rparent"]
+    return out
+
+
+if __name__ == "__main__":
+    main()
