@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: RNEA + d(tau)/dz sample-evals/s (fp64).
 
-  python bench.py --gpus N --steps K --warmup W [--workload kinova|talos|g1]
+  python bench.py --gpus N --steps K --warmup W [--workload kinova|talos|g1|digit]
   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Default workload = BASELINE.json configs[1] (Kinova): a *step* is one pass of the hot path (eval_g + eval_jac_g, i.e.
@@ -81,7 +81,30 @@ class Legged:
         return H.legged_problem(api, self.name, keep, N=self.samples)[0]
 
 
-WORKLOADS = {"kinova": Kinova, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1")}
+class Digit:
+    """BASELINE configs[3] (north_star target: >= 1e7 sample-evals/s on one MI355X)."""
+    name = "digit"
+    samples = 14
+    batch = 4096
+    rows = 12 + 36 + 7
+    bytes_per_se = rows * 8 * (132 + 1)   # 8 R (V + 1) for the rows built (torque, joint limits, contact)
+    flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
+    dominant = 1
+    kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows)",
+               "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
+    pmc_key = "legged_expand_kernel"
+    z_scale = 0.1  # DigitSingleStep.cpp:75
+    workload = ("Digit-v3 single-step gait, nv=36 (6 floating + 12 actuated + 18 closed-loop), Bezier degree 5, "
+                "14 Chebyshev samples x 4096 random z in 0.1*U(-1,1)^132 per GPU, eval_g+eval_jac_g "
+                "(torque limits + constrained joint limits + rectangle contact), no solver")
+
+    def build(self, api, keep):
+        import helpers as H
+
+        return H.digit_problem(api, keep, N=self.samples)[0]
+
+
+WORKLOADS = {"kinova": Kinova, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1"), "digit": Digit}
 
 
 def main() -> None:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libraptor_hip.so")
 SOURCES = ["raptor_hip.hip"]
-HEADERS = ["kernels.h", "kinova_kernel.h", "legged_kernel.h", "capsule_kernel.h", "spatial_dev.h", "device_types.h", os.path.join("..", "..", "include", "raptor_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "raptor_hip.h")]
 
 
 def hipcc() -> str:

@@ -81,6 +81,18 @@ struct DevLegged {
     double Ades[9];                           // inverse of d(rpy)/d(omega) at R_des; lambda_rot = Ades^T n_p
     double p_foot[3];                         // contact point (stance_foot_T_des.p)
     double mu, gamma, Lx, Ly;                 // RectangleSurfaceContactConstraints
+    // closed loops (Digit): a tree joint that is not driven by the trajectory is a function of <= 2 independent joints.
+    // Every tree joint carries <= 2 chain-rule weight slots (G, Hv, Hq) towards minimal (independent) columns.
+    int nrec;                                 // dependent loop joints per sample-eval (0: Talos / G1, 18: Digit)
+    int body_rec[RAPTOR_LEG_MAX_BODIES];      // record of the body's joint in the loop buffer, -1: driven by the trajectory
+    int body_col[RAPTOR_LEG_MAX_BODIES][2];   // minimal column of weight slot 0 / 1 (-1: unused)
+    int col_nsupp[RAPTOR_LEG_MAX_IND];        // tree joints that move with independent joint t ...
+    int col_supp_body[RAPTOR_LEG_MAX_IND][8]; // ... their bodies ...
+    int col_supp_slot[RAPTOR_LEG_MAX_IND][8]; // ... and which of their weight slots points at t
+    int ind_ndep[RAPTOR_LEG_MAX_IND];         // dependent loop joints of independent joint t
+    int ind_dep_body[RAPTOR_LEG_MAX_IND][6];
+    int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)
+    int ind_loop_col[RAPTOR_LEG_MAX_IND][2];  // minimal columns of the drivers (a, b) of t's loop, -1: none
     int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
     // per-sample-eval record written by the core kernel (doubles)
     int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_stride;

@@ -36,7 +36,10 @@ template <int LG>
 struct LegLds {
     static constexpr int X = 0;                 // phase-0 exchange: qd, qdd, cos q, sin q, q per body
     static constexpr int V = LG * 5;            // per-joint vectors
-    static constexpr int STRIDE = V + LG * LEG_VEC + 2;
+    static constexpr int W = V + LG * LEG_VEC;  // chain-rule weights: 2 slots x (G, Hv, Hq) per joint
+    static constexpr int TT = W + LG * 6;       // tree-joint torques
+    static constexpr int TS = TT + LG;          // per-column scratch: T_q, T_v, T_a per joint
+    static constexpr int STRIDE = TS + LG * 3 + 2;
 };
 
 // Utils::wrapToPi (Utils/include/Utils.h:59-68)
@@ -99,7 +102,7 @@ template <int LG, bool DERIV>
 __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
-    double* __restrict__ G, double* __restrict__ core) {
+    const double* __restrict__ loops, double* __restrict__ G, double* __restrict__ core) {
     extern __shared__ double lds[];
     using LL = LegLds<LG>;
     constexpr int EPB = LEG_BLOCK / LG;
@@ -121,17 +124,38 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     const int gb = has_body ? g : 0;
     const int jnt = has_joint ? Q->body_joint[gb] : 0;
     const int tj = has_joint ? Q->body_traj[gb] : -1;
+    const int rc = has_joint ? Q->body_rec[gb] : -1;
     const int gend = has_body ? Q->body_end[gb] : LG;
+    const double* lr = (rc >= 0) ? loops + ((size_t)e * Q->nrec + rc) * 10 : nullptr;
 
-    // ---- phase 0: this body's joint: trajectory value and sincos ----
+    // ---- phase 0: this body's joint value, rates, chain-rule weights towards the independent columns, sincos ----
     double q = 0.0, qd = 0.0, qdd = 0.0, sq = 0.0, cq = 1.0;
+    double w0[3] = {1.0, 0.0, 0.0}, w1[3] = {0.0, 0.0, 0.0};
     if (tj >= 0) {
         traj_joint(T, basis, z, i, tj, q, qd, qdd);
-        sincos(q, &sq, &cq);
+    } else if (rc >= 0) {
+        // closed-loop joint: theta = y(x), theta' = Y1 x', theta'' = Y1 x'' + x'^T Y2 x'   (digit_kernel.h records)
+        const int ca = Q->body_col[gb][0], cb = Q->body_col[gb][1];
+        double xa, xda, xdda, xb = 0.0, xdb = 0.0, xddb = 0.0;
+        traj_joint(T, basis, z, i, ca, xa, xda, xdda);
+        if (cb >= 0) traj_joint(T, basis, z, i, cb, xb, xdb, xddb);
+        q = lr[0];
+        qd = lr[1] * xda + lr[2] * xdb;
+        qdd = lr[1] * xdda + lr[2] * xddb + lr[3] * xda * xda + 2.0 * lr[4] * xda * xdb + lr[5] * xdb * xdb;
+        w0[0] = lr[1];
+        w0[1] = 2.0 * (lr[3] * xda + lr[4] * xdb);
+        w0[2] = lr[3] * xdda + lr[4] * xddb + lr[6] * xda * xda + 2.0 * lr[7] * xda * xdb + lr[8] * xdb * xdb;
+        w1[0] = lr[2];
+        w1[1] = 2.0 * (lr[4] * xda + lr[5] * xdb);
+        w1[2] = lr[4] * xdda + lr[5] * xddb + lr[7] * xda * xda + 2.0 * lr[8] * xda * xdb + lr[9] * xdb * xdb;
     }
     if (has_joint) {
+        sincos(q, &sq, &cq);
         double* x = sl + LL::X + g * 5;
         x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
+        double* ww = sl + LL::W + g * 6;
+        ww[0] = w0[0]; ww[1] = w0[1]; ww[2] = w0[2];
+        ww[3] = w1[0]; ww[4] = w1[1]; ww[5] = w1[2];
     }
     wave_sync();
 
@@ -246,20 +270,28 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
     if (has_joint) {
-        // ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
-        const double tau = dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd;
+        // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
+        sl[LL::TT + g] = dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd;
         rec[Q->c_q + jnt] = q;
         rec[Q->c_v + jnt] = qd;
         rec[Q->c_a + jnt] = qdd;
-        if (tj >= 0) {
-            rec[Q->c_tau + tj] = tau;
-            if (G != nullptr) {
-                G[rowbase + Q->off_tau + (size_t)i * ni + tj] = tau;                 // TorqueLimits.cpp:30-34
-                G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);        // ConstrainedJointLimits.cpp:57
-            }
-        }
+        if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);  // ConstrainedJointLimits.cpp:57
     }
-    if (g == 0) {  // root: contact wrench lambda = [f ; A_des^T (n - p x f)]   (== J_dep^-T tau_dep, ConstrainedInverseDynamics.cpp:154)
+    wave_sync();
+    const int myslot = (tj >= 0) ? Q->ind_slot[tj] : 0;
+    const int ndep = (tj >= 0) ? Q->ind_ndep[tj] : 0;
+    if (tj >= 0) {
+        // actuated torque = G^T tau_tree: own joint plus the closed-loop joints this actuator drives
+        // (== tau_indep - J_indep^T lambda, ConstrainedInverseDynamics.cpp:175)
+        double tau = sl[LL::TT + g];
+        for (int d = 0; d < ndep; d++) {
+            const int db = Q->ind_dep_body[tj][d];
+            tau += sl[LL::W + db * 6 + myslot * 3] * sl[LL::TT + db];
+        }
+        rec[Q->c_tau + tj] = tau;
+        if (G != nullptr) G[rowbase + Q->off_tau + (size_t)i * ni + tj] = tau;  // TorqueLimits.cpp:30-34
+    }
+    if (g == 0) {  // root: contact wrench lambda = [f ; A_des^T (n - p x f)]   (== tail of J_dep^-T tau_dep, :154)
         const V3 np = F.a - cross(pf, F.l);
         double lam[6] = {F.l.x, F.l.y, F.l.z,
                          Q->Ades[0] * np.x + Q->Ades[3] * np.y + Q->Ades[6] * np.z,
@@ -279,7 +311,8 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
             gc[6] = -Ly * lam[2] - lam[4];
         }
     }
-    if (has_body && g == Q->torso_body) {
+    const bool is_torso = has_body && g == Q->torso_body;
+    if (is_torso) {
         // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
         const V3 rpy = v3(atan2(-Rw.m[5], Rw.m[8]), safe_asin(Rw.m[2]), atan2(-Rw.m[1], Rw.m[0]));
         const V3 pd = v.l + cross(v.a, ow);
@@ -326,55 +359,71 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
             lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
         }
     }
-    // the torso's pose is needed for P_dep: broadcast from the torso's lane (12 shuffles)
-    M3 Rt;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rt.m[k] = __shfl(Rw.m[k], Q->torso_body, LG);
-    const V3 ot = v3(__shfl(ow.x, Q->torso_body, LG), __shfl(ow.y, Q->torso_body, LG), __shfl(ow.z, Q->torso_body, LG));
+    // (dG^T/dq) tau_tree: an actuator's torque also changes because the loop Jacobian Y1 moves with the drivers
+    double Kq[2] = {0.0, 0.0};
+    for (int d = 0; d < ndep; d++) {
+        const int db = Q->ind_dep_body[tj][d];
+        const double* ld = loops + ((size_t)e * Q->nrec + Q->body_rec[db]) * 10;
+        const double td = sl[LL::TT + db];
+        Kq[0] += ld[3 + myslot] * td;
+        Kq[1] += ld[4 + myslot] * td;
+    }
+    const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
+    if (rc >= 0) {  // P_dep rows of the closed-loop joints (= Y1, DigitDynamicsConstraints.cpp:394)
+        const int di = Q->joint_dep[jnt];
+        const int ca = Q->body_col[gb][0], cb = Q->body_col[gb][1];
+        for (int c = 0; c < ni; c++) rec[Q->c_P + di * ni + c] = (c == ca) ? w0[0] : ((c == cb) ? w1[0] : 0.0);
+    }
     wave_sync();
 
-    // P_dep column of this joint (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246): the torso moves with this
-    // joint iff the torso body is in this joint's subtree
-    if (tj >= 0) {
-        const bool moves = Q->torso_body >= g && Q->torso_body < gend;
-        const V3 lin = s.l + cross(s.a, ot);
-        const V3 rot = rpy_rates(Rt, s.a);
-        const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
-#pragma unroll
-        for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + tj] = moves ? pc[k] : 0.0;
-    }
-
-    // ---- phase F: D_q, D_v, D_a (rows = this lane's joint, columns = independent joints) and d(lambda) ----
+    // ---- phase F: for every independent joint `it`: d(tree torques, root wrench, torso twist)/d(q, v, a)_it ----
 #pragma unroll 1
     for (int it = 0; it < ni; it++) {
-        const int k = Q->ind_body[it];
-        const int kend = Q->body_end[k];
-        const double* vk = sl + LL::V + k * LEG_VEC;
-        if (tj >= 0) {
-            double dq, dv, da;
-            if (k > g && k < gend) {  // this joint is a strict ancestor of k
-                da = dot(s, lds_sv(vk + 18));
-                dv = dot(s, lds_sv(vk + 24));
-                dq = dot(s, lds_sv(vk + 30));
-            } else if (g >= k && g < kend) {  // k is this joint or one of its ancestors
-                const SV sk = lds_sv(vk), sdk = lds_sv(vk + 6), psik = lds_sv(vk + 12);
-                da = dot(IS, sk);
-                dv = 2.0 * dot(IS, sdk) + dot(BtS, sk);
-                dq = dot(IS, psik) + dot(BtS, sdk);
-                if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
-                    da += M->armature[jnt];
-                    dv += M->damping[jnt];
+        const int ns = Q->col_nsupp[it];
+        double Tq = 0.0, Tv = 0.0, Ta = 0.0;
+        SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), tw = sv_zero();
+        for (int r = 0; r < ns; r++) {
+            const int k = Q->col_supp_body[it][r];
+            const int kend = Q->body_end[k];
+            const double* vk = sl + LL::V + k * LEG_VEC;
+            const double* wk = sl + LL::W + k * 6 + Q->col_supp_slot[it][r] * 3;
+            const double g0 = wk[0], hv = wk[1], hq = wk[2];
+            if (has_joint) {
+                double dq = 0.0, dv = 0.0, da = 0.0;
+                if (k > g && k < gend) {  // this joint is a strict ancestor of k
+                    da = dot(s, lds_sv(vk + 18));
+                    dv = dot(s, lds_sv(vk + 24));
+                    dq = dot(s, lds_sv(vk + 30));
+                } else if (g >= k && g < kend) {  // k is this joint or one of its ancestors
+                    const SV sk = lds_sv(vk), sdk = lds_sv(vk + 6), psik = lds_sv(vk + 12);
+                    da = dot(IS, sk);
+                    dv = 2.0 * dot(IS, sdk) + dot(BtS, sk);
+                    dq = dot(IS, psik) + dot(BtS, sdk);
+                    if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
+                        da += M->armature[jnt];
+                        dv += M->damping[jnt];
+                    }
                 }
-            } else {
-                da = dv = dq = 0.0;
+                Ta += da * g0;
+                Tv += dv * g0 + da * hv;
+                Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
             }
-            double* D = rec + Q->c_D + (size_t)(tj * 3) * ni + it;
-            D[0] = dq; D[ni] = dv; D[2 * ni] = da;
+            if (g == 0) {  // root wrench
+                const SV ISk = lds_sv(vk + 18), cvk = lds_sv(vk + 24), cqk = lds_sv(vk + 30);
+                Fa = Fa + ISk * g0;
+                Fv = Fv + cvk * g0 + ISk * hv;
+                Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
+            }
+            if (is_torso && g >= k && g < kend) tw = tw + lds_sv(vk) * g0;  // torso twist per unit rate of `it`
         }
-        if (g == 0) {  // d(root wrench) for a unit (q, v, a) change of joint k, mapped like lambda
+        if (has_joint) {
+            double* ts = sl + LL::TS + g * 3;
+            ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
+        }
+        if (g == 0) {  // d(lambda.tail(6))
 #pragma unroll
             for (int x = 0; x < 3; x++) {
-                const SV w = lds_sv(vk + (x == 0 ? 30 : (x == 1 ? 24 : 18)));
+                const SV w = (x == 0) ? Fq : ((x == 1) ? Fv : Fa);
                 const V3 np = w.a - cross(pf, w.l);
                 const double lm[6] = {w.l.x, w.l.y, w.l.z,
                                       Q->Ades[0] * np.x + Q->Ades[3] * np.y + Q->Ades[6] * np.z,
@@ -384,6 +433,28 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
                 for (int r = 0; r < 6; r++) rec[Q->c_L + (size_t)(r * 3 + x) * ni + it] = lm[r];
             }
         }
+        if (is_torso) {  // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
+            const V3 lin = tw.l + cross(tw.a, ow);
+            const V3 rot = rpy_rates(Rw, tw.a);
+            const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
+#pragma unroll
+            for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + it] = pc[k];
+        }
+        wave_sync();
+        if (tj >= 0) {  // project the rows: G^T
+            double Rq = Tq, Rv = Tv, Ra = Ta;
+            for (int d = 0; d < ndep; d++) {
+                const int db = Q->ind_dep_body[tj][d];
+                const double gd = sl[LL::W + db * 6 + myslot * 3];
+                const double* ts = sl + LL::TS + db * 3;
+                Rq += gd * ts[0]; Rv += gd * ts[1]; Ra += gd * ts[2];
+            }
+            if (it == lc0) Rq += Kq[0];
+            if (it == lc1) Rq += Kq[1];
+            double* D = rec + Q->c_D + (size_t)(tj * 3) * ni + it;
+            D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
+        }
+        wave_sync();
     }
 }
 

@@ -17,6 +17,9 @@
 #include "capsule_kernel.h"
 #include "kinova_kernel.h"
 #include "legged_kernel.h"
+#include "digit_kernel.h"
+#include "digit_constants.h"
+#include "digit_tables.h"
 
 namespace {
 
@@ -95,6 +98,9 @@ struct raptor_problem {
     DevLegged hleg;
     DevBuf<DevLegged> d_leg;
     DevBuf<double> s_core;  // per-sample records of the legged core kernel (grown on demand, reused)
+    bool has_digit = false;
+    DevBuf<DevDigit> d_digit;
+    DevBuf<double> s_loops;  // per-sample closed-loop records (digit_kernel.h)
     DevModel hmodel;
     DevTraj htraj;
     DevSpheres hspheres;
@@ -303,6 +309,18 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
     p.s_core.ensure((size_t)E * p.hleg.c_stride);
+    const double* d_loops = nullptr;
+    if (p.has_digit) {  // closed loops first: one lane per (sample-eval, leg), knee and toe loops in separate launches
+        p.s_loops.ensure((size_t)E * p.hleg.nrec * DIGIT_REC);
+        const long long total = E * 2;
+        const unsigned lgrid = (unsigned)((total + 63) / 64);
+        hipLaunchKernelGGL((digit_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
+                           p.layout.n, dZ, total, p.s_loops.p);
+        hipLaunchKernelGGL((digit_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
+                           p.layout.n, dZ, total, p.s_loops.p);
+        HIP_CHECK(hipGetLastError());
+        d_loops = p.s_loops.p;
+    }
     const bool wide = p.hleg.nb > 16;
     const int LG = wide ? 32 : 16;
     const int epb = LEG_BLOCK / LG;
@@ -310,7 +328,7 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const unsigned grid = (unsigned)((E + epb - 1) / epb);
 #define LEG_LAUNCH(LGV, DV)                                                                                          \
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
-                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, dG, p.s_core.p)
+                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, dG, p.s_core.p)
     if (wide) {
         if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
     } else {
@@ -532,69 +550,79 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     API_CATCH
 }
 
-int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_desc* d, raptor_problem** out) {
-    API_TRY
-    if (!model || !d || !out) throw std::invalid_argument("null argument");
-    std::unique_ptr<raptor_problem> p(new raptor_problem());
+// what legged_setup needs beyond the model: the arguments of the single-step optimizers that reach the hot path
+struct LeggedSetup {
+    const raptor_traj_desc* traj;
+    int extra_variables;
+    std::vector<int> dep, ind;          // model joint indices, reference order (floating base first)
+    int contact_joint_id;               // Pinocchio id (1-based)
+    double endT_R[9], endT_p[3];        // stance_foot_endT
+    const double *Tdes_R, *Tdes_p;
+    const double *tl, *tu, *jl, *ju;
+    double mu, gamma, Lx, Ly;
+    // closed loops: for a dependent joint that is not part of the floating base, its record and its driving joints
+    std::vector<int> loop_rec, loop_drv_a, loop_drv_b;  // indexed by model joint, -1: none
+    int nrec = 0;
+};
+
+static void legged_setup(raptor_problem& pr, const raptor_model* model, const LeggedSetup& S) {
+    raptor_problem* p = &pr;
     p->kind = 2;
     p->hmodel = model->h;
     const DevModel& m = p->hmodel;
     const int nv = m.nv;
-    if (d->traj.type != RAPTOR_TRAJ_BEZIER) throw std::invalid_argument("single-step optimizers use BezierCurves");
+    if (S.traj->type != RAPTOR_TRAJ_BEZIER) throw std::invalid_argument("single-step optimizers use BezierCurves");
     std::vector<double> basis, wsum;
-    fill_traj(&d->traj, p->htraj, p->tspan, basis, wsum);
-    if (d->extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
-    p->htraj.varLength += d->extra_variables;  // TalosSingleStepOptimizer.cpp:50-51
-    const int N = p->htraj.N, ni = d->num_independent, nd = d->num_dependent, K = p->htraj.degree + 1;
-    if (nd != 6) throw std::invalid_argument("contact constraint: six dependent joints expected");
+    fill_traj(S.traj, p->htraj, p->tspan, basis, wsum);
+    if (S.extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
+    p->htraj.varLength += S.extra_variables;  // TalosSingleStepOptimizer.cpp:50-51, DigitSingleStepOptimizer.cpp:50-51
+    const int N = p->htraj.N, ni = (int)S.ind.size(), nd = (int)S.dep.size(), K = p->htraj.degree + 1;
     if (ni != p->htraj.Nact || nd + ni != nv)
         throw std::invalid_argument("Trajectory and DynamicsConstraints must have the same number of actuated joints");
-    if (!d->dependent_ids || !d->independent_ids || !d->torque_limits_lower || !d->torque_limits_upper ||
-        !d->joint_limits_lower || !d->joint_limits_upper)
-        throw std::invalid_argument("null array");
+    if (!S.tl || !S.tu || !S.jl || !S.ju) throw std::invalid_argument("null array");
     if (ni > RAPTOR_LEG_MAX_IND) throw unsupported_error("legged kernel: at most 12 independent joints");
     DevLegged& Q = p->hleg;
     std::memset(&Q, 0, sizeof(Q));
-    Q.ni = ni; Q.nd = nd; Q.nv = nv; Q.K = K;
+    Q.ni = ni; Q.nd = nd; Q.nv = nv; Q.K = K; Q.nrec = S.nrec;
     for (int j = 0; j < nv; j++) Q.joint_ind[j] = Q.joint_dep[j] = -1;
     for (int k = 0; k < nd; k++) {
-        const int id = d->dependent_ids[k];
+        const int id = S.dep[k];
         if (id < 0 || id >= nv || Q.joint_dep[id] >= 0) throw std::invalid_argument("bad dependent joint id");
         Q.joint_dep[id] = k;
         Q.dep_joint[k] = id;
     }
     for (int k = 0; k < ni; k++) {
-        const int id = d->independent_ids[k];
+        const int id = S.ind[k];
         if (id < 0 || id >= nv || Q.joint_dep[id] >= 0 || Q.joint_ind[id] >= 0) throw std::invalid_argument("bad independent joint id");
         Q.joint_ind[id] = k;
         Q.ind_joint[k] = id;
     }
-    if (d->contact_joint_id < 1 || d->contact_joint_id > nv || d->fk_start_joint < 0 || d->fk_start_joint > nv)
-        throw std::runtime_error("Can not find joint");
+    if (S.contact_joint_id < 1 || S.contact_joint_id > nv) throw std::runtime_error("Can not find joint");
     // the floating base the closed form of TalosDynamicsConstraints.cpp:208-222 assumes: Px,Py,Pz,Rx,Ry,Rz in a chain
     // from the world, identity placements, massless intermediate links, no joint-space extras
     static const int base_types[6] = {4, 5, 6, 1, 2, 3};
+    std::vector<int> is_base(nv, 0);
     for (int k = 0; k < 6; k++) {
         const int id = Q.dep_joint[k];
         bool ok = m.jtype[id] == base_types[k] && m.parent[id] == (k == 0 ? -1 : Q.dep_joint[k - 1]);
         for (int t = 0; t < 9; t++) ok = ok && std::fabs(m.plR[id][t] - ((t % 4 == 0) ? 1.0 : 0.0)) < 1e-12;
         for (int t = 0; t < 3; t++) ok = ok && std::fabs(m.plp[id][t]) < 1e-12;
         ok = ok && (k == 5 || m.mass[id] == 0.0) && m.armature[id] == 0.0 && m.damping[id] == 0.0;
-        if (!ok) throw unsupported_error("legged kernel: the dependent joints must be a Px,Py,Pz,Rx,Ry,Rz floating base");
+        if (!ok) throw unsupported_error("legged kernel: the first six dependent joints must be a Px,Py,Pz,Rx,Ry,Rz floating base");
+        is_base[id] = 1;
     }
     const int torso_link = Q.dep_joint[5];
-    if (d->fk_start_joint != torso_link + 1) throw unsupported_error("legged kernel: fk_start_joint must be the last floating-base joint");
-    const int foot_link = d->contact_joint_id - 1;
-    if (Q.joint_ind[foot_link] < 0) throw unsupported_error("legged kernel: the stance foot joint must be an independent joint");
+    const int foot_link = S.contact_joint_id - 1;
+    if (is_base[foot_link]) throw unsupported_error("legged kernel: the stance foot cannot be a floating-base joint");
     for (int j = 0; j < nv; j++)
-        if (Q.joint_dep[j] < 0 && (m.parent[j] < 0 || (Q.joint_dep[m.parent[j]] >= 0 && m.parent[j] != torso_link)))
+        if (!is_base[j] && (m.parent[j] < 0 || (is_base[m.parent[j]] && m.parent[j] != torso_link)))
             throw unsupported_error("legged kernel: every leg must hang from the last floating-base link");
 
     // re-root at the stance-foot link: DFS pre-order over the links joined by the non-base joints
     struct Edge { int joint, other, rev; };
     std::vector<std::vector<Edge>> adj(nv);
     for (int j = 0; j < nv; j++) {
-        if (Q.joint_dep[j] >= 0) continue;
+        if (is_base[j]) continue;
         adj[j].push_back(Edge{j, m.parent[j], 1});
         adj[m.parent[j]].push_back(Edge{j, j, 0});
     }
@@ -609,7 +637,17 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
         Q.body_rparent[idx] = rparent;
         Q.body_depth[idx] = depth;
         Q.body_traj[idx] = via >= 0 ? Q.joint_ind[via] : -1;
-        if (via >= 0 && Q.joint_ind[via] < 0) throw unsupported_error("legged kernel: closed-loop dependent joints are not built yet");
+        Q.body_rec[idx] = -1;
+        Q.body_col[idx][0] = Q.body_traj[idx];
+        Q.body_col[idx][1] = -1;
+        if (via >= 0 && Q.joint_ind[via] < 0) {
+            const int rc = (int)S.loop_rec.size() == nv ? S.loop_rec[via] : -1;
+            if (rc < 0) throw unsupported_error("legged kernel: dependent joint outside the floating base without a closed loop");
+            if (m.jtype[via] > 3 || m.jtype[via] < -3) throw unsupported_error("legged kernel: closed-loop joints must be revolute");
+            Q.body_rec[idx] = rc;
+            Q.body_col[idx][0] = Q.joint_ind[S.loop_drv_a[via]];
+            Q.body_col[idx][1] = S.loop_drv_b[via] >= 0 ? Q.joint_ind[S.loop_drv_b[via]] : -1;
+        }
         for (int t = 0; t < depth - 1; t++) Q.path[idx][t] = Q.path[rparent][t];
         if (depth > 0) Q.path[idx][depth - 1] = idx;
         if (link == torso_link) Q.torso_body = idx;
@@ -619,24 +657,49 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
     };
     visit(foot_link, -1, 0, -1, 0);
     Q.nb = nb;
-    if (nb != ni + 1) throw unsupported_error("legged kernel: every non-base joint must be reachable from the stance foot");
-    for (int g = 1; g < nb; g++) Q.ind_body[Q.body_traj[g]] = g;
+    if (nb != nv - 6 + 1) throw unsupported_error("legged kernel: every non-base joint must be reachable from the stance foot");
+    for (int t = 0; t < ni; t++) {
+        Q.ind_loop_col[t][0] = Q.ind_loop_col[t][1] = -1;
+    }
+    for (int g = 1; g < nb; g++) {
+        if (Q.body_traj[g] >= 0) Q.ind_body[Q.body_traj[g]] = g;
+        for (int slot = 0; slot < 2; slot++) {
+            const int t = Q.body_col[g][slot];
+            if (t < 0) continue;
+            if (Q.col_nsupp[t] >= 8) throw unsupported_error("legged kernel: more than 8 joints move with one actuator");
+            Q.col_supp_body[t][Q.col_nsupp[t]] = g;
+            Q.col_supp_slot[t][Q.col_nsupp[t]] = slot;
+            Q.col_nsupp[t]++;
+            if (Q.body_rec[g] >= 0) {
+                if (Q.ind_ndep[t] >= 6) throw unsupported_error("legged kernel: more than 6 loop joints per actuator");
+                Q.ind_dep_body[t][Q.ind_ndep[t]++] = g;
+                Q.ind_slot[t] = slot;
+                Q.ind_loop_col[t][0] = Q.body_col[g][0];
+                Q.ind_loop_col[t][1] = Q.body_col[g][1];
+            }
+        }
+    }
 
+    // root body frame = T_des * endT^-1   (TalosDynamicsConstraints.cpp:34-38,214-218; Digit: rotated end transform)
     for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) Q.R0[3 * r + c] = d->stance_foot_T_des_R[3 * r + c];
-        Q.p_foot[r] = d->stance_foot_T_des_p[r];
+        for (int c = 0; c < 3; c++) {
+            double sum = 0;
+            for (int k = 0; k < 3; k++) sum += S.Tdes_R[3 * r + k] * S.endT_R[3 * c + k];  // R_des * R_e^T
+            Q.R0[3 * r + c] = sum;
+        }
+        Q.p_foot[r] = S.Tdes_p[r];
     }
     for (int r = 0; r < 3; r++) {
-        double s = 0;
-        for (int c = 0; c < 3; c++) s += Q.R0[3 * r + c] * d->stance_foot_endT_p[c];
-        Q.o0[r] = Q.p_foot[r] - s;  // T_des * endT^-1 (pure translation end transform, TalosDynamicsConstraints.cpp:34-38)
+        double sum = 0;
+        for (int c = 0; c < 3; c++) sum += Q.R0[3 * r + c] * S.endT_p[c];
+        Q.o0[r] = Q.p_foot[r] - sum;
     }
     {   // A_des = W^-1, W = d(rpy)/d(omega) at R_des
         double W[9];
         for (int k = 0; k < 3; k++) {
             double w[3] = {0, 0, 0}, o[3];
             w[k] = 1.0;
-            rpy_rates(Q.R0, w, o);
+            rpy_rates(S.Tdes_R, w, o);
             for (int r = 0; r < 3; r++) W[3 * r + k] = o[r];
         }
         const double det = W[0] * (W[4] * W[8] - W[5] * W[7]) - W[1] * (W[3] * W[8] - W[5] * W[6]) + W[2] * (W[3] * W[7] - W[4] * W[6]);
@@ -646,25 +709,25 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
         Q.Ades[3] = (W[5] * W[6] - W[3] * W[8]) * id; Q.Ades[4] = (W[0] * W[8] - W[2] * W[6]) * id; Q.Ades[5] = (W[2] * W[3] - W[0] * W[5]) * id;
         Q.Ades[6] = (W[3] * W[7] - W[4] * W[6]) * id; Q.Ades[7] = (W[1] * W[6] - W[0] * W[7]) * id; Q.Ades[8] = (W[0] * W[4] - W[1] * W[3]) * id;
     }
-    Q.mu = d->mu; Q.gamma = d->gamma; Q.Lx = d->Lx; Q.Ly = d->Ly;
+    Q.mu = S.mu; Q.gamma = S.gamma; Q.Lx = S.Lx; Q.Ly = S.Ly;
 
-    // layout, TalosSingleStepOptimizer.cpp:69-92: [torque limits | joint limits | contact]
-    const int rt = N * ni, rq = N * nv, rc = N * 7;
+    // layout, TalosSingleStepOptimizer.cpp:69-92 / DigitSingleStepOptimizer.cpp:74-94: [torque limits | joint limits | contact]
+    const int rt = N * ni, rq = N * nv, rcn = N * 7;
     Q.off_tau = 0; Q.off_q = rt; Q.off_contact = rt + rq;
     std::memset(&p->hspheres, 0, sizeof(p->hspheres));
-    p->layout = DevLayout{rt + rq + rc, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
+    p->layout = DevLayout{rt + rq + rcn, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
     p->num_blocks = 3;
-    p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rc;
+    p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rcn;
     p->g_lb.assign(p->layout.m, 0.0);
     p->g_ub.assign(p->layout.m, 0.0);
     for (int i = 0; i < N; i++) {
         for (int j = 0; j < ni; j++) {  // TorqueLimits.cpp:45-50
-            p->g_lb[i * ni + j] = d->torque_limits_lower[j];
-            p->g_ub[i * ni + j] = d->torque_limits_upper[j];
+            p->g_lb[i * ni + j] = S.tl[j];
+            p->g_ub[i * ni + j] = S.tu[j];
         }
         for (int j = 0; j < nv; j++) {  // ConstrainedJointLimits.cpp:73-78
-            p->g_lb[rt + i * nv + j] = d->joint_limits_lower[j];
-            p->g_ub[rt + i * nv + j] = d->joint_limits_upper[j];
+            p->g_lb[rt + i * nv + j] = S.jl[j];
+            p->g_ub[rt + i * nv + j] = S.ju[j];
         }
         p->g_lb[rt + rq + i * 7] = 0;  // RectangleSurfaceContactConstraints.cpp:97-125
         p->g_ub[rt + rq + i * 7] = 1e19;
@@ -687,14 +750,151 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
 
     upload_common(*p, basis, wsum);
     p->d_leg.upload(&Q, 1);
+}
+
+int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_desc* d, raptor_problem** out) {
+    API_TRY
+    if (!model || !d || !out) throw std::invalid_argument("null argument");
+    if (d->num_dependent != 6) throw std::invalid_argument("contact constraint: six dependent joints expected");
+    if (!d->dependent_ids || !d->independent_ids) throw std::invalid_argument("null array");
+    if (d->num_independent < 1 || d->num_independent > RAPTOR_MAX_NV) throw std::invalid_argument("bad num_independent");
+    std::unique_ptr<raptor_problem> p(new raptor_problem());
+    LeggedSetup S;
+    S.traj = &d->traj;
+    S.extra_variables = d->extra_variables;
+    S.dep.assign(d->dependent_ids, d->dependent_ids + 6);
+    S.ind.assign(d->independent_ids, d->independent_ids + d->num_independent);
+    S.contact_joint_id = d->contact_joint_id;
+    if (d->fk_start_joint != d->dependent_ids[5] + 1)
+        throw unsupported_error("legged kernel: fk_start_joint must be the last floating-base joint");
+    for (int k = 0; k < 9; k++) S.endT_R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int k = 0; k < 3; k++) S.endT_p[k] = d->stance_foot_endT_p[k];
+    S.Tdes_R = d->stance_foot_T_des_R;
+    S.Tdes_p = d->stance_foot_T_des_p;
+    S.tl = d->torque_limits_lower; S.tu = d->torque_limits_upper;
+    S.jl = d->joint_limits_lower; S.ju = d->joint_limits_upper;
+    S.mu = d->mu; S.gamma = d->gamma; S.Lx = d->Lx; S.Ly = d->Ly;
+    legged_setup(*p, model, S);
     *out = p.release();
     API_CATCH
+}
+
+static void fill_chain_joint(const DevModel& m, int joint, int var, DevChainJoint& cj) {
+    for (int k = 0; k < 9; k++) cj.plR[k] = m.plR[joint][k];
+    for (int k = 0; k < 3; k++) cj.plp[k] = m.plp[joint][k];
+    cj.jtype = m.jtype[joint];
+    cj.var = var;
 }
 
 int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_desc* d, raptor_problem** out) {
     API_TRY
     if (!model || !d || !out) throw std::invalid_argument("null argument");
-    throw unsupported_error("Digit closed-loop kernel: not built yet");
+    const DevModel& m = model->h;
+    const int nv = m.nv;
+    if (nv != 36) throw std::invalid_argument("Digit: NUM_JOINTS is 36");
+    if (d->stance_leg != 'L' && d->stance_leg != 'R' && d->stance_leg != 'l' && d->stance_leg != 'r')
+        throw std::runtime_error("Invalid stance leg input");
+    const int sleg = (d->stance_leg == 'L' || d->stance_leg == 'l') ? 0 : 1;
+    std::vector<int> seen(nv, 0);
+    auto take = [&](int id) {
+        if (id < 0 || id >= nv || seen[id]++) throw std::runtime_error("Can not find joint");
+        return id;
+    };
+    LeggedSetup S;
+    S.traj = &d->traj;
+    S.extra_variables = d->extra_variables;
+    for (int k = 0; k < 6; k++) S.dep.push_back(take(d->base_ids[k]));  // DigitDynamicsConstraints.h:19-57 order
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 9; k++) S.dep.push_back(take(d->leg_ids[leg][DIGIT_LEG_DEPENDENT[k]]));
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 6; k++) S.ind.push_back(take(d->leg_ids[leg][DIGIT_LEG_INDEPENDENT[k]]));
+    S.contact_joint_id = d->leg_ids[sleg][DG_TOE_ROLL] + 1;
+    digit_stance_foot_endT(sleg, S.endT_R, S.endT_p);
+    S.Tdes_R = d->stance_foot_T_des_R;
+    S.Tdes_p = d->stance_foot_T_des_p;
+    S.tl = d->torque_limits_lower; S.tu = d->torque_limits_upper;
+    S.jl = d->joint_limits_lower; S.ju = d->joint_limits_upper;
+    S.mu = d->mu; S.gamma = d->gamma; S.Lx = d->Lx; S.Ly = d->Ly;
+
+    // loops: per leg a knee loop (records 0..2) and a toe loop (records 3..8); 18 records per sample-eval
+    std::unique_ptr<DevDigit> D(new DevDigit());
+    std::memset(D.get(), 0, sizeof(DevDigit));
+    D->recs_per_sample = 18;
+    for (int k = 0; k < 16; k++) {
+        D->pair_idx[k][0] = DIGIT_TOE_PAIR[k][0];
+        D->pair_idx[k][1] = DIGIT_TOE_PAIR[k][1];
+    }
+    S.loop_rec.assign(nv, -1);
+    S.loop_drv_a.assign(nv, -1);
+    S.loop_drv_b.assign(nv, -1);
+    S.nrec = 18;
+    std::vector<int> ind_of(nv, -1);
+    for (size_t t = 0; t < S.ind.size(); t++) ind_of[S.ind[t]] = (int)t;
+    for (int leg = 0; leg < 2; leg++) {
+        const int* ids = d->leg_ids[leg];
+        for (int type = 0; type < 2; type++) {  // 0 knee, 1 toe
+            DevLoop& L = D->loop[leg][type];
+            const DigitLoop& ref = DIGIT_LOOPS[type == 0 ? 2 : 0];
+            L.ny = ref.ndep; L.nx = ref.ndrv; L.ncl = type == 0 ? 1 : 2;
+            L.rec0 = leg * 9 + (type == 0 ? 0 : 3);
+            // local variables: unknowns first (role order of ref.depj), then the drivers
+            auto var_of = [&](int role) {
+                for (int r = 0; r < ref.ndep; r++) if (ref.depj[r] == role) return r;
+                for (int x = 0; x < ref.ndrv; x++) if (ref.drv[x] == role) return ref.ndep + x;
+                throw std::runtime_error("Digit loop: joint outside the loop");
+            };
+            for (int c = 0; c < L.ncl; c++) {
+                const DigitLoop& lp = DIGIT_LOOPS[type == 0 ? 2 : c];
+                DevClosure& cl = L.cl[c];
+                // chains from lp.start (exclusive) to endA / endB, following the model's parents
+                auto chain = [&](int end_role, std::vector<int>& roles) {
+                    roles.clear();
+                    int j = ids[end_role];
+                    const int stop = ids[lp.start];
+                    while (j != stop) {
+                        int role = -1;
+                        for (int r = 0; r < DG_LEG_JOINTS; r++) if (ids[r] == j) role = r;
+                        if (role < 0 || roles.size() > 3) throw std::runtime_error("Digit loop: chain leaves the leg");
+                        roles.insert(roles.begin(), role);
+                        j = m.parent[j];
+                        if (j < 0) throw std::runtime_error("Digit loop: chain does not reach its base link");
+                    }
+                };
+                std::vector<int> ra, rb;
+                chain(lp.endA, ra);
+                chain(lp.endB, rb);
+                if ((int)ra.size() != (type == 0 ? 2 : 3) || rb.size() != 2) throw unsupported_error("Digit loop: unexpected chain length");
+                cl.nA = (int)ra.size(); cl.nB = (int)rb.size();
+                for (size_t k = 0; k < ra.size(); k++) fill_chain_joint(m, ids[ra[k]], var_of(ra[k]), cl.A[k]);
+                for (size_t k = 0; k < rb.size(); k++) fill_chain_joint(m, ids[rb[k]], var_of(rb[k]), cl.B[k]);
+                double an[3] = {lp.anchor[leg][0], lp.anchor[leg][1], lp.anchor[leg][2]};
+                if (type == 0) digit_knee_anchor(leg, an);
+                for (int k = 0; k < 3; k++) { cl.endA[k] = lp.rod[k]; cl.endB[k] = an[k]; }
+            }
+            for (int x = 0; x < ref.ndrv; x++) L.drv_traj[x] = ind_of[ids[ref.drv[x]]];
+            for (int r = 0; r < ref.ndep; r++) {
+                const int j = ids[ref.depj[r]];
+                S.loop_rec[j] = L.rec0 + r;
+                S.loop_drv_a[j] = ids[ref.drv[0]];
+                S.loop_drv_b[j] = ref.ndrv > 1 ? ids[ref.drv[1]] : -1;
+                if (type == 1) {
+                    const DigitToeGuess& g = DIGIT_TOE_GUESS[leg][r];
+                    L.g_sign[r] = g.sign; L.g_c0[r] = g.c0;
+                    for (int k = 0; k < 8; k++) L.g_lin[r][k] = g.lin[k];
+                    for (int k = 0; k < 16; k++) L.g_pair[r][k] = g.pair[k];
+                } else {
+                    const DigitKneeGuess& g = DIGIT_KNEE_GUESS[leg][r];
+                    L.g_sign[r] = g.sign; L.g_c0[r] = g.c0;
+                    for (int k = 0; k < 4; k++) L.g_lin[r][k] = g.lin[k];
+                }
+            }
+        }
+    }
+    std::unique_ptr<raptor_problem> p(new raptor_problem());
+    legged_setup(*p, model, S);
+    p->d_digit.upload(D.get(), 1);
+    p->has_digit = true;
+    *out = p.release();
     API_CATCH
 }
 
@@ -706,7 +906,7 @@ int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, d
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
     const DevLegged& Q = p->hleg;
-    const int N = p->htraj.N, n = p->layout.n, nv = Q.nv, ni = Q.ni, nd = Q.nd;
+    const int N = p->htraj.N, n = p->layout.n, nv = Q.nv, ni = Q.ni, nd = 6;  // lambda.tail(6)
     const bool deriv = ptau_pz != nullptr || plambda_pz != nullptr;
     const size_t E = (size_t)B * N;
     p->s_Z.upload(Z, (size_t)B * n);

@@ -321,3 +321,87 @@ def test_legged_full_size_properties(hip):
         kinked[p.block_offsets[2] + 7 * i + 2] = True
     assert err[:, ~kinked].max().item() < 1e-6
     assert (err[:, kinked] < 1e-6).double().mean().item() > 0.99
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Digit-v3: closed kinematic loops (knee / toe rods) + planted stance foot
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stance", ["L", "R"])
+def test_digit_constrained_inverse_dynamics(oracle, hip, stance):
+    """DigitConstrainedInverseDynamics::compute members per sample: q (all 36, closed loops solved), v, a, tau,
+    lambda.tail(6), ptau_pz, plambda_pz."""
+    N = 5
+    keep = []
+    po, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance)
+    ph, _, _ = H.digit_problem(hip, keep, N=N, stance=stance)
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    rng = np.random.default_rng(20250523 + 4)
+    Z = 0.1 * rng.uniform(-1, 1, (4, po.n))  # DigitSingleStep.cpp:75 scale
+    ro = po.constrained_id_host(Z, N, 36, 12)
+    rh = ph.constrained_id_host(Z, N, 36, 12)
+    for key in ("q", "v", "a", "tau", "lam", "ptau_pz", "plambda_pz"):
+        check(rh[key], ro[key])
+    assert np.all(rh["ptau_pz"][..., 72:] == 0)
+    rh2 = ph.constrained_id_host(Z, N, 36, 12, derivatives=False)
+    for key in ("q", "v", "a", "tau", "lam"):
+        check(rh2[key], ro[key])
+
+
+def test_digit_eval_g_and_jac(oracle, hip):
+    """eval_g / eval_jac_g of DigitSingleStepOptimizer's first three blocks at the example's size (N = 14, degree 5)."""
+    keep = []
+    po, m, cfg = H.digit_problem(oracle, keep, N=14)
+    ph, _, _ = H.digit_problem(hip, keep, N=14)
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets) == (132, 14 * 55, [0, 168, 672, 770])
+    lo, uo = po.bounds()
+    lh, uh = ph.bounds()
+    assert np.array_equal(lo, lh) and np.array_equal(uo, uh)
+    rng = np.random.default_rng(20250523 + 4)
+    Z = 0.1 * rng.uniform(-1, 1, (5, 132))
+    Z[-1] *= 3.0
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    assert np.all(Jh[:, :, 72:] == 0.0) and np.all(Jo[:, :, 72:] == 0.0)
+    Gh2, none = ph.eval_host(Z, A.EVAL_G)
+    check(Gh2, Gh, 1e-12)
+
+
+def test_digit_full_size_properties(hip):
+    """BASELINE config 3 at a large batch (Digit, 1024 z x N = 14) through the device entry point."""
+    import torch
+
+    keep = []
+    p, m, cfg = H.digit_problem(hip, keep, N=14)
+    B = 1024
+    g = torch.Generator(device="cpu").manual_seed(20250528)
+    Z = (0.1 * (torch.rand(B, p.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
+    G = torch.empty(B, p.m, dtype=torch.float64, device="cuda")
+    J = torch.full((B, p.m, p.n), float("nan"), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    p.eval_device(Z.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G.data_ptr(), J.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(G).all() and torch.isfinite(J).all()
+    perm = torch.randperm(B, generator=g).cuda()
+    G2, J2 = torch.empty_like(G), torch.empty_like(J)
+    Zp = Z[perm].contiguous()
+    p.eval_device(Zp.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G2.data_ptr(), J2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(G2, G[perm]) and torch.equal(J2, J[perm])
+    d = torch.randn(B, p.n, generator=g, dtype=torch.float64).cuda()
+    h = 1e-6
+    G3 = torch.empty_like(G)
+    Zh, Zm = (Z + h * d).contiguous(), (Z - h * d).contiguous()
+    p.eval_device(Zh.data_ptr(), B, A.EVAL_G, G2.data_ptr(), 0, st)
+    p.eval_device(Zm.data_ptr(), B, A.EVAL_G, G3.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    num = (G2 - G3) / (2 * h)
+    ana = torch.einsum("bmn,bn->bm", J, d)
+    err = (num - ana).abs() / (1 + ana.abs().max().item())
+    kinked = torch.zeros(p.m, dtype=torch.bool, device="cuda")
+    for i in range(14):
+        kinked[p.block_offsets[2] + 7 * i + 1] = True
+        kinked[p.block_offsets[2] + 7 * i + 2] = True
+    assert err[:, ~kinked].max().item() < 1e-6
+    assert (err[:, kinked] < 1e-6).double().mean().item() > 0.99
