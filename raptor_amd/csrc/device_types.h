@@ -93,9 +93,12 @@ struct DevLegged {
     int ind_dep_body[RAPTOR_LEG_MAX_IND][6];
     int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)
     int ind_loop_col[RAPTOR_LEG_MAX_IND][2];  // minimal columns of the drivers (a, b) of t's loop, -1: none
+    int dep_col[RAPTOR_MAX_NV][2];            // by dependent index (>= 6): minimal columns of its two P_dep entries
     int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
-    // per-sample-eval record written by the core kernel (doubles)
-    int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_stride;
+    // per-sample-eval record written by the core kernel (doubles):
+    //   tau[ni] lambda[6] q[nv] v[nv] a[nv] | D[it][x][ni] (x = q, v, a; rows = actuators) | L[it][x][6] |
+    //   Pb[it][6] (floating-base rows of P_dep) | Pl[nd - 6][2] (closed-loop rows of P_dep, columns dep_col)
+    int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_Pl, c_stride;
 };
 
 // where each constraint block of this problem starts in the Optimizer's row order (-1: block absent)

@@ -370,9 +370,9 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     }
     const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
     if (rc >= 0) {  // P_dep rows of the closed-loop joints (= Y1, DigitDynamicsConstraints.cpp:394)
-        const int di = Q->joint_dep[jnt];
-        const int ca = Q->body_col[gb][0], cb = Q->body_col[gb][1];
-        for (int c = 0; c < ni; c++) rec[Q->c_P + di * ni + c] = (c == ca) ? w0[0] : ((c == cb) ? w1[0] : 0.0);
+        double* pl = rec + Q->c_Pl + (Q->joint_dep[jnt] - 6) * 2;
+        pl[0] = w0[0];
+        pl[1] = w1[0];
     }
     wave_sync();
 
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
                                       Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
                                       Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
 #pragma unroll
-                for (int r = 0; r < 6; r++) rec[Q->c_L + (size_t)(r * 3 + x) * ni + it] = lm[r];
+                for (int r = 0; r < 6; r++) rec[Q->c_L + (it * 3 + x) * 6 + r] = lm[r];
             }
         }
         if (is_torso) {  // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
             const V3 rot = rpy_rates(Rw, tw.a);
             const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
-            for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + it] = pc[k];
+            for (int k = 0; k < 6; k++) rec[Q->c_P + it * 6 + k] = pc[k];
         }
         wave_sync();
         if (tj >= 0) {  // project the rows: G^T
@@ -451,73 +451,157 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
             }
             if (it == lc0) Rq += Kq[0];
             if (it == lc1) Rq += Kq[1];
-            double* D = rec + Q->c_D + (size_t)(tj * 3) * ni + it;
+            double* D = rec + Q->c_D + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
             D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
         }
         wave_sync();
     }
 }
 
-// One Jacobian entry of the problem's row r (within one decision vector), column c.
-RD double legged_jac_entry(const DevLegged* __restrict__ Q, const double* __restrict__ basis,
-                           const double* __restrict__ core, long long b, int N, int r, int c) {
-    const int ni = Q->ni, K = Q->K, nv = Q->nv;
-    if (c >= ni * K) return 0.0;  // v_reset / lambda_reset columns never enter these blocks (TalosSingleStepOptimizer.cpp:50-51)
-    const int t = c / K, k = c - t * K;
-    int i, lr, kind;
-    if (r >= Q->off_tau && r < Q->off_tau + N * ni) {
-        kind = 0; i = (r - Q->off_tau) / ni; lr = (r - Q->off_tau) - i * ni;
-    } else if (r >= Q->off_q && r < Q->off_q + N * nv) {
-        kind = 1; i = (r - Q->off_q) / nv; lr = (r - Q->off_q) - i * nv;
-    } else {
-        kind = 2; i = (r - Q->off_contact) / 7; lr = (r - Q->off_contact) - i * 7;
-    }
-    const double* Bs = basis + (size_t)(i * 3) * K + k;
-    const double B0 = Bs[0], B1 = Bs[K], B2 = Bs[2 * K];
-    const double* rec = core + (size_t)(b * N + i) * Q->c_stride;
-    if (kind == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
-        const double* D = rec + Q->c_D + (size_t)(lr * 3) * ni + t;
-        return D[0] * B0 + D[ni] * B1 + D[2 * ni] * B2;
-    }
-    if (kind == 1) {  // ConstrainedJointLimits.cpp:59-68
-        const int ti = Q->joint_ind[lr];
-        if (ti >= 0) return (ti == t) ? B0 : 0.0;
-        return rec[Q->c_P + Q->joint_dep[lr] * ni + t] * B0;
-    }
-    double p[6];  // RectangleSurfaceContactConstraints.cpp:52-93
+// Streams pg_pz out in Optimizer order.  One workgroup per sample-eval: the sample's record and the per-column Bernstein
+// weights are staged in LDS once; the three row blocks of this sample are contiguous pieces of the output
+// (rows i*R .. i*R + R - 1 of a block), written with one 16-byte store per lane and no integer division in the loop.
+//   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
+//   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
+template <int PIECE>
+RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, double* __restrict__ dst,
+                            const double* __restrict__ rec, const double* __restrict__ wB, const int* __restrict__ tcol,
+                            const int* __restrict__ rowinfo, const DevLegged* __restrict__ Q) {
+    const double* D = rec + Q->c_D;
+    const double* Lm = rec + Q->c_L;
+    const double* Pb = rec + Q->c_P;
+    const double* Pl = rec + Q->c_Pl;
+    const double* lam = rec + Q->c_lam;
+    const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
+    const int dr = (2 * RAPTOR_BLOCK) / n, dc = (2 * RAPTOR_BLOCK) - dr * n;
+    const int total = R * n;
+    int el = 2 * tid;
+    int r = el / n, c = el - r * n;
+    for (; el < total; el += 2 * RAPTOR_BLOCK) {
+        double o[2];
 #pragma unroll
-    for (int rr = 0; rr < 6; rr++) {
-        const double* Lm = rec + Q->c_L + (size_t)(rr * 3) * ni + t;
-        p[rr] = Lm[0] * B0 + Lm[ni] * B1 + Lm[2 * ni] * B2;
+        for (int h = 0; h < 2; h++) {
+            const int cc = c + h;
+            double val = 0.0;
+            if (cc < ndyn) {  // the v_reset / lambda_reset tail never enters (TalosSingleStepOptimizer.cpp:50-51)
+                const int t = tcol[cc];
+                const double B0 = wB[cc];
+                if (PIECE == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
+                    const double* d = D + (t * 3) * ni + r;
+                    val = d[0] * B0 + d[ni] * wB[ndyn + cc] + d[2 * ni] * wB[2 * ndyn + cc];
+                } else if (PIECE == 1) {  // ConstrainedJointLimits.cpp:59-68
+                    const int info = rowinfo[r];  // >= 0: independent index; < 0: -1 - dependent index
+                    if (info >= 0) {
+                        val = (info == t) ? B0 : 0.0;
+                    } else {
+                        const int dd = -1 - info;
+                        double g;
+                        if (dd < 6) g = Pb[t * 6 + dd];
+                        else g = (t == rowinfo[RAPTOR_MAX_NV + 2 * dd]) ? Pl[(dd - 6) * 2] : ((t == rowinfo[RAPTOR_MAX_NV + 2 * dd + 1]) ? Pl[(dd - 6) * 2 + 1] : 0.0);
+                        val = g * B0;
+                    }
+                } else {  // RectangleSurfaceContactConstraints.cpp:52-93
+                    double p[6];
+                    const double B1 = wB[ndyn + cc], B2 = wB[2 * ndyn + cc];
+                    const double* l = Lm + (t * 3) * 6;
+#pragma unroll
+                    for (int rr = 0; rr < 6; rr++) p[rr] = l[rr] * B0 + l[6 + rr] * B1 + l[12 + rr] * B2;
+                    val = contact_row(r, lam, p, mu, gam, Lx, Ly);
+                }
+            }
+            o[h] = val;
+        }
+        *reinterpret_cast<double2*>(dst + el) = make_double2(o[0], o[1]);
+        r += dr;
+        c += dc;
+        if (c >= n) { c -= n; r++; }
     }
-    return contact_row(lr, rec + Q->c_lam, p, Q->mu, Q->gamma, Q->Lx, Q->Ly);
 }
 
-// Streams pg_pz out in Optimizer order: each lane owns two adjacent columns of one row (one 16-byte store).
 __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTraj* __restrict__ T,
                                                                      const DevLegged* __restrict__ Q,
                                                                      const double* __restrict__ basis, const DevLayout L,
-                                                                     const double* __restrict__ core, const int tiles_per_z,
+                                                                     const double* __restrict__ core,
                                                                      double* __restrict__ JAC) {
-    const long long b = blockIdx.x / tiles_per_z;
-    const int tile = (int)(blockIdx.x - b * tiles_per_z);
-    const int el = 2 * (tile * RAPTOR_BLOCK + (int)threadIdx.x);
-    const int total = L.m * L.n;
-    if (el >= total) return;
-    const int r = el / L.n, c = el - r * L.n;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const long long e = blockIdx.x;
     const int N = T->N;
-    double2 out;
-    out.x = legged_jac_entry(Q, basis, core, b, N, r, c);
-    if (el + 1 >= total) {  // odd m * n: last entry alone
-        JAC[(size_t)b * total + el] = out.x;
-        return;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    const int ni = Q->ni, nv = Q->nv, nd = Q->nd, K = Q->K, n = L.n;
+    const int ndyn = ni * K;
+    const int stride = Q->c_stride;
+    double* rec = lds;
+    double* wB = lds + stride;                                   // [3][ndyn]
+    int* tcol = reinterpret_cast<int*>(wB + 3 * ndyn);           // [ndyn]
+    int* rowinfo = tcol + ndyn;                                  // [MAX_NV] row kind, then [MAX_NV][2] dep_col
+    const double* src = core + (size_t)e * stride;
+    for (int k = tid; k < stride; k += RAPTOR_BLOCK) rec[k] = src[k];
+    for (int c = tid; c < ndyn; c += RAPTOR_BLOCK) {
+        const int t = c / K, k = c - t * K;
+        const double* Bs = basis + (size_t)(i * 3) * K + k;
+        wB[c] = Bs[0];
+        wB[ndyn + c] = Bs[K];
+        wB[2 * ndyn + c] = Bs[2 * K];
+        tcol[c] = t;
     }
-    if (c + 1 < L.n) {
-        out.y = legged_jac_entry(Q, basis, core, b, N, r, c + 1);
-    } else {  // odd n: the pair straddles two rows
-        out.y = legged_jac_entry(Q, basis, core, b, N, r + 1, 0);
+    if (tid < nv) rowinfo[tid] = (Q->joint_ind[tid] >= 0) ? Q->joint_ind[tid] : -1 - Q->joint_dep[tid];
+    if (tid < nd) {
+        rowinfo[RAPTOR_MAX_NV + 2 * tid] = Q->dep_col[tid][0];
+        rowinfo[RAPTOR_MAX_NV + 2 * tid + 1] = Q->dep_col[tid][1];
     }
-    *reinterpret_cast<double2*>(JAC + (size_t)b * total + el) = out;
+    __syncthreads();
+    // the three row blocks of this sample are contiguous pieces of the output; 16-byte aligned because n is even
+    double* base = JAC + (size_t)b * L.m * n;
+    legged_expand_piece<0>(tid, n, ndyn, ni, ni, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, wB, tcol, rowinfo, Q);
+    legged_expand_piece<1>(tid, n, ndyn, ni, nv, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, wB, tcol, rowinfo, Q);
+    legged_expand_piece<2>(tid, n, ndyn, ni, 7, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, wB, tcol, rowinfo, Q);
+}
+
+// fallback for an odd number of columns: one entry per lane
+__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(const DevTraj* __restrict__ T,
+                                                                            const DevLegged* __restrict__ Q,
+                                                                            const double* __restrict__ basis, const DevLayout L,
+                                                                            const double* __restrict__ core, const long long total,
+                                                                            double* __restrict__ JAC) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int n = L.n, N = T->N, ni = Q->ni, nv = Q->nv, K = Q->K;
+    const int c = (int)(w % n);
+    const long long br = w / n;
+    const int r = (int)(br % L.m);
+    const long long b = br / L.m;
+    double val = 0.0;
+    if (c < ni * K) {
+        const int t = c / K, k = c - t * K;
+        int i, lr, piece;
+        if (r >= Q->off_tau && r < Q->off_tau + N * ni) { piece = 0; i = (r - Q->off_tau) / ni; lr = (r - Q->off_tau) - i * ni; }
+        else if (r >= Q->off_q && r < Q->off_q + N * nv) { piece = 1; i = (r - Q->off_q) / nv; lr = (r - Q->off_q) - i * nv; }
+        else { piece = 2; i = (r - Q->off_contact) / 7; lr = (r - Q->off_contact) - i * 7; }
+        const double* Bs = basis + (size_t)(i * 3) * K + k;
+        const double B0 = Bs[0], B1 = Bs[K], B2 = Bs[2 * K];
+        const double* rec = core + (size_t)(b * N + i) * Q->c_stride;
+        if (piece == 0) {
+            const double* d = rec + Q->c_D + (t * 3) * ni + lr;
+            val = d[0] * B0 + d[ni] * B1 + d[2 * ni] * B2;
+        } else if (piece == 1) {
+            const int ti = Q->joint_ind[lr];
+            if (ti >= 0) val = (ti == t) ? B0 : 0.0;
+            else {
+                const int dd = Q->joint_dep[lr];
+                if (dd < 6) val = rec[Q->c_P + t * 6 + dd] * B0;
+                else val = ((t == Q->dep_col[dd][0]) ? rec[Q->c_Pl + (dd - 6) * 2] : ((t == Q->dep_col[dd][1]) ? rec[Q->c_Pl + (dd - 6) * 2 + 1] : 0.0)) * B0;
+            }
+        } else {
+            double p[6];
+            const double* l = rec + Q->c_L + (t * 3) * 6;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) p[rr] = l[rr] * B0 + l[6 + rr] * B1 + l[12 + rr] * B2;
+            val = contact_row(lr, rec + Q->c_lam, p, Q->mu, Q->gamma, Q->Lx, Q->Ly);
+        }
+    }
+    JAC[w] = val;
 }
 
 // ConstrainedInverseDynamics::ptau_pz / plambda_pz view for the parity entry point: [B][N][rows][n]
@@ -540,8 +624,9 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_id_kernel(const De
         const int i = (int)(e % T->N);
         const double* Bs = basis + (size_t)(i * 3) * K + k;
         const double* rec = core + (size_t)e * Q->c_stride;
-        const double* D = rec + (lambda_rows ? Q->c_L : Q->c_D) + (size_t)(lr * 3) * ni + t;
-        val = D[0] * Bs[0] + D[ni] * Bs[K] + D[2 * ni] * Bs[2 * K];
+        const int R = lambda_rows ? 6 : ni;
+        const double* D = rec + (lambda_rows ? Q->c_L : Q->c_D) + (t * 3) * R + lr;
+        val = D[0] * Bs[0] + D[R] * Bs[K] + D[2 * R] * Bs[2 * K];
     }
     out[w] = val;
 }

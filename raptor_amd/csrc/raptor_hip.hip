@@ -343,11 +343,19 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     launch_legged_core(p, dZ, B, dG, jac, st);
     if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
-    const long long total = (long long)p.layout.m * p.layout.n;
-    const int tiles = (int)((total / 2 + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK);
-    if ((long long)tiles * B > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
-    hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)((long long)tiles * B)), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p,
-                       p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, tiles, dJ);
+    const long long E = (long long)B * p.htraj.N;
+    if (p.layout.n % 2 == 0 && ((size_t)dJ & 15) == 0) {
+        if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+        const int ndyn = p.hleg.ni * p.hleg.K;
+        const size_t lds_bytes = (size_t)(p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
+        hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)E), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_leg.p,
+                           p.d_basis.p, p.layout, p.s_core.p, dJ);
+    } else {
+        const long long total = (long long)B * p.layout.m * p.layout.n;
+        if (total / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+        hipLaunchKernelGGL(legged_expand_scalar_kernel, dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_leg.p,
+                           p.d_basis.p, p.layout, p.s_core.p, total, dJ);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
@@ -745,8 +753,17 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     Q.c_a = off; off += nv;
     Q.c_D = off; off += ni * 3 * ni;
     Q.c_L = off; off += 6 * 3 * ni;
-    Q.c_P = off; off += nd * ni;
+    Q.c_P = off; off += ni * 6;
+    Q.c_Pl = off; off += (nd - 6) * 2;
     Q.c_stride = (off + 1) & ~1;
+    for (int dd = 6; dd < nd; dd++) {
+        Q.dep_col[dd][0] = Q.dep_col[dd][1] = -1;
+        for (int g = 1; g < nb; g++)
+            if (Q.body_joint[g] == Q.dep_joint[dd]) {
+                Q.dep_col[dd][0] = Q.body_col[g][0];
+                Q.dep_col[dd][1] = Q.body_col[g][1];
+            }
+    }
 
     upload_common(*p, basis, wsum);
     p->d_leg.upload(&Q, 1);

@@ -283,6 +283,24 @@ def test_legged_rotated_stance_foot_and_degree(oracle, hip):
     check(Jh, Jo)
 
 
+def test_legged_odd_number_of_columns(oracle, hip):
+    """varLength odd (109): the streaming kernel's scalar fallback writes the same rows."""
+    keep = []
+    po, m, cfg = H.legged_problem(oracle, "g1", keep, N=3)
+    cfg.extra_variables = 25
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, 3, 12, cfg.degree, A.TIME_CHEBYSHEV)
+    mo, mh = oracle.model_create(m), hip.model_create(m)
+    keep += [mo, mh]
+    po = A.ProblemHandle.legged(oracle, mo, t, cfg)
+    ph = A.ProblemHandle.legged(hip, mh, t, cfg)
+    assert po.n == ph.n == 109
+    Z = 0.1 * np.random.default_rng(9).uniform(-1, 1, (3, 109))
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+
+
 def test_legged_full_size_properties(hip):
     """BASELINE config 5 size on one GPU's shard (G1, 1024 problems x N = 14) through the device entry point."""
     import torch
