@@ -1,0 +1,56 @@
+"""Generates tests/golden/*.npz: small input/output vectors of the hot path.
+
+The reference holds no golden vectors at fixed z for this path and cannot be built or imported here, so
+these are REGRESSION vectors produced by the CPU oracle in this container (fixed seeds), after the oracle was pinned
+by tests/test_oracle_pins.py and tests/test_oracle_legged.py.  The only reference-held answers, the nine
+TaperedCapsuleCollision cases, are stored verbatim in capsule_known_answers.json.
+    python scripts/gen_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H
+import raptor_amd
+from raptor_amd import _capi as A
+from test_oracle_pins import CAPSULE_KNOWN
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
+    keep = []
+    kin = raptor_amd.load_urdf(os.path.join(ROOT, "tests", "robots", "kinova.urdf"))
+    kin.gravity = np.array([0.0, 0.0, -9.81])
+    p = H.kinova_problem(oracle, kin, keep, N=4, boxes=H.reach_boxes())
+    Z = np.random.default_rng(20250523).uniform(-1, 1, (2, 7))
+    G, J = p.eval_host(Z)
+    np.savez(os.path.join(OUT, "kinova_N4.npz"), Z=Z, G=G, J=J, block_offsets=np.array(p.block_offsets))
+    for which in ("talos", "g1"):
+        p, m, cfg = H.legged_problem(oracle, which, keep, N=2)
+        Z = 0.1 * np.random.default_rng(20250523 + len(which)).uniform(-1, 1, (1, p.n))
+        G, J = p.eval_host(Z)
+        r = p.constrained_id_host(Z, 2, m.nv, 12)
+        np.savez(os.path.join(OUT, f"{which}_N2.npz"), Z=Z, G=G, J=J, q=r["q"], tau=r["tau"], lam=r["lam"],
+                 block_offsets=np.array(p.block_offsets))
+    p, m, cfg = H.digit_problem(oracle, keep, N=2)
+    Z = 0.1 * np.random.default_rng(20250523 + 36).uniform(-1, 1, (1, p.n))
+    G, J = p.eval_host(Z)
+    r = p.constrained_id_host(Z, 2, 36, 12)
+    np.savez(os.path.join(OUT, "digit_N2.npz"), Z=Z, G=G, J=J, q=r["q"], tau=r["tau"], lam=r["lam"],
+             block_offsets=np.array(p.block_offsets))
+    json.dump([dict(p11=c[0], p12=c[1], p21=c[2], p22=c[3], r11=c[4], r12=c[5], r21=c[6], r22=c[7], distance=c[8])
+               for c in CAPSULE_KNOWN], open(os.path.join(OUT, "capsule_known_answers.json"), "w"), indent=1)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

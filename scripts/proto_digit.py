@@ -139,11 +139,9 @@ class Loop:
         return Y1, Y2, Y3, it
 
 
-def main():
+def run(stance="L", N=4, verbose=False):
     oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
-    N = 4
     keep = []
-    stance = sys.argv[1] if len(sys.argv) > 1 else "L"
     p, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance)
     sleg = 0 if stance == "L" else 1
     nv = m.nv
@@ -162,7 +160,8 @@ def main():
     foot = cfg.leg_ids[sleg][R_["toe_roll"]]
     bodies = PR.reroot(m, foot)
     nb = len(bodies)
-    print("bodies", nb, "max depth", max(len(_path(bodies, g)) for g in range(nb)))
+    if verbose:
+        print("bodies", nb, "max depth", max(len(_path(bodies, g)) for g in range(nb)))
     body_of_joint = {bodies[g]["joint"]: g for g in range(1, nb)}
     torso = [g for g in range(nb) if bodies[g]["link"] == 5][0]
     # root pose: T_des * endT^-1
@@ -254,7 +253,11 @@ def main():
         for jj in dep_all:
             row = Jref[0, off + i * nv + jj].reshape(-1)[:12 * K].reshape(12, K)
             upd("P_dep", P[jj] * basis[i, 0, 2], row[:, 2])
-    print(worst)
+    return worst
+
+
+def main():
+    print(run(sys.argv[1] if len(sys.argv) > 1 else "L", verbose=True))
 
 
 def _path(bodies, g):

@@ -128,14 +128,11 @@ def evaluate(m, cfg, bodies, qj, vj, aj_):
     return out
 
 
-def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "talos"
+def run(which="talos", N=5):
     oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
-    N = 5
     m, cfg, p, keep = build(oracle, which, N)
     bodies = reroot(m, cfg.contact_joint_id - 1)
     nb = len(bodies)
-    print(which, "bodies", [(b["link"], b["joint"], int(b["rev"]), b["rparent"], b["end"]) for b in bodies])
     rng = np.random.default_rng(3)
     Z = 0.3 * rng.uniform(-1, 1, (1, p.n))
     ref = p.constrained_id_host(Z, N, m.nv, 12, 6, True)
@@ -180,7 +177,11 @@ def main():
                 ptau[:, t * K + c] = [r["Cq"][rr, k] * w0 + r["Cv"][rr, k] * w1 + r["Mt"][rr, k] * w2 for rr in rows]
                 plam[:, t * K + c] = L @ (r["FQ"][:, k] * w0 + r["FV"][:, k] * w1 + r["FA"][:, k] * w2)
         upd("ptau_pz", ptau, ref["ptau_pz"][0, i]); upd("plambda_pz", plam, ref["plambda_pz"][0, i])
-    print(worst)
+    return worst
+
+
+def main():
+    print(run(sys.argv[1] if len(sys.argv) > 1 else "talos"))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,107 @@
+"""Pins the legged / Digit part of the CPU oracle (runs without a GPU).
+
+The reference holds no golden vectors for this path: its own criterion is finite differences (whole-
+problem derivative check 1e-4, DigitSingleStep.cpp:119-131; TestInverseDynamics.cpp 1e-5).  On top of that recipe the
+oracle -- a literal restatement of DynamicsConstraints / ConstrainedInverseDynamics with FK Hessians, third-order
+tensors and dense solves -- is cross-checked against an INDEPENDENT formulation (numpy, scripts/proto_*.py: fixed-base
+tree re-rooted at the stance foot, implicit loop derivatives), and against statics (contact force = total weight).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def _fd(p, Z, N, nv, cols, h=1e-6):
+    ref = p.constrained_id_host(Z, N, nv, 12)
+    fd_t = np.zeros_like(ref["ptau_pz"][0])
+    fd_l = np.zeros_like(ref["plambda_pz"][0])
+    for c in cols:
+        zp, zm = Z.copy(), Z.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        a = p.constrained_id_host(zp, N, nv, 12, derivatives=False)
+        b = p.constrained_id_host(zm, N, nv, 12, derivatives=False)
+        fd_t[:, :, c] = (a["tau"][0] - b["tau"][0]) / (2 * h)
+        fd_l[:, :, c] = (a["lam"][0] - b["lam"][0]) / (2 * h)
+    et = np.abs(fd_t[:, :, cols] - ref["ptau_pz"][0][:, :, cols]).max() / (1 + np.abs(fd_t).max())
+    el = np.abs(fd_l[:, :, cols] - ref["plambda_pz"][0][:, :, cols]).max() / (1 + np.abs(fd_l).max())
+    return et, el, ref
+
+
+@pytest.mark.parametrize("which", ["talos", "g1"])
+def test_contact_constrained_id_finite_differences(oracle, which):
+    keep = []
+    p, m, cfg = H.legged_problem(oracle, which, keep, N=3)
+    Z = 0.3 * np.random.default_rng(1).uniform(-1, 1, (1, p.n))
+    et, el, ref = _fd(p, Z, 3, m.nv, list(range(0, 84, 5)))
+    assert et < 1e-7 and el < 1e-7, (et, el)
+    assert np.all(ref["ptau_pz"][..., 84:] == 0)
+
+
+@pytest.mark.parametrize("stance", ["L", "R"])
+def test_digit_constrained_id_finite_differences(oracle, stance):
+    keep = []
+    p, m, cfg = H.digit_problem(oracle, keep, N=3, stance=stance)
+    Z = 0.1 * np.random.default_rng(2).uniform(-1, 1, (1, p.n))
+    et, el, ref = _fd(p, Z, 3, 36, list(range(0, 72, 5)))
+    assert et < 1e-7 and el < 1e-7, (et, el)
+
+
+@pytest.mark.parametrize("robot", ["talos", "g1", "digit"])
+def test_static_contact_wrench_is_the_weight(oracle, robot):
+    """q constant (all Bezier coefficients of a joint equal): v = a = 0, so lambda = (0, 0, m g, mx, my, 0)."""
+    keep = []
+    if robot == "digit":
+        p, m, cfg = H.digit_problem(oracle, keep, N=3)
+        K, g = 6, 9.806
+    else:
+        p, m, cfg = H.legged_problem(oracle, robot, keep, N=3)
+        K, g = 7, 9.81
+    q0 = 0.1 * np.random.default_rng(3).uniform(-1, 1, 12)
+    Z = np.zeros((1, p.n))
+    Z[0, : 12 * K] = np.repeat(q0, K)
+    r = p.constrained_id_host(Z, 3, m.nv, 12, derivatives=False)
+    assert np.abs(r["v"]).max() < 1e-12 and np.abs(r["a"]).max() < 1e-10
+    lam = r["lam"][0, 0]
+    assert abs(lam[2] - m.mass.sum() * g) < 1e-9 and np.abs(lam[[0, 1, 5]]).max() < 1e-9
+
+
+@pytest.mark.parametrize("which", ["talos", "g1"])
+def test_independent_formulation_contact(oracle, which):
+    import proto_rerooted
+
+    worst = proto_rerooted.run(which, N=3)
+    assert max(worst.values()) < 1e-11, worst
+
+
+@pytest.mark.parametrize("stance", ["L", "R"])
+def test_independent_formulation_digit(oracle, stance):
+    import proto_digit
+
+    worst = proto_digit.run(stance, N=2)
+    assert max(worst.values()) < 1e-10, worst
+
+
+def test_digit_layout_bounds_and_errors(oracle):
+    from raptor_amd import _capi as A
+
+    keep = []
+    p, m, cfg = H.digit_problem(oracle, keep, N=14)
+    assert (p.n, p.m, p.block_offsets) == (132, 770, [0, 168, 672, 770])  # DigitSingleStepOptimizer.cpp:74-94 at N = 14
+    lb, ub = p.bounds()
+    assert lb[0] == -113.0 and ub[3] == 231.317                            # DigitConstants.h:96-123
+    assert np.isclose(lb[168 + 6], np.deg2rad(-60)) and np.isclose(ub[168 + 8], np.deg2rad(90))
+    assert np.all(lb[672::7] == 0) and np.all(ub[672::7] == 1e19) and np.all(ub[673::7] == 0)
+    cfg.stance_leg = "x"
+    mh = oracle.model_create(m)
+    keep.append(mh)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, 4, 12, cfg.degree, A.TIME_CHEBYSHEV)
+    with pytest.raises(A.RaptorError):
+        A.ProblemHandle.digit(oracle, mh, t, cfg)
