@@ -243,6 +243,25 @@ int raptor_capsule_distance_batch_host(const double* P, const double* dP, const 
 int raptor_profile_begin(raptor_problem* problem, int max_evaluations);
 int raptor_profile_end(raptor_problem* problem, int* evaluations, double* id_ms_avg, double* obs_ms_avg);
 
+/*
+ * Costs::compute for the cost classes the single-step optimizers use (Costs/include/Costs.h:25-45):
+ *   RAPTOR_COST_MINIMIZE_POWER                 MinimizePower::compute               Costs/src/MinimizePower.cpp:12-71
+ *   RAPTOR_COST_MINIMIZE_TORQUE                MinimizeTorque::compute              Costs/src/MinimizeTorque.cpp:12-63
+ *   RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY      MinimizeInitialVelocity::compute     Costs/src/MinimizeInitialVelocity.cpp:10-41
+ *   RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION  MinimizeInitialAcceleration::compute (same form on q_dd(0))
+ * F [B][num_costs] = the members `f`, GRAD [B][num_costs][n] = `grad_f` (NULL: compute_derivatives = false).  The weighted sum
+ * of Optimizer::eval_f / eval_grad_f (Optimization/src/Optimizer.cpp:201-295) stays with the caller.  Legged / Digit
+ * problems only (the torques are ConstrainedInverseDynamics::tau).
+ */
+#define RAPTOR_COST_MINIMIZE_POWER 0
+#define RAPTOR_COST_MINIMIZE_TORQUE 1
+#define RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY 2
+#define RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION 3
+int raptor_eval_costs(raptor_problem* problem, const double* d_Z, int B, int num_costs, const int* kinds, double* d_F,
+                      double* d_GRAD, void* stream);
+int raptor_eval_costs_host(raptor_problem* problem, const double* Z, int B, int num_costs, const int* kinds, double* F,
+                           double* GRAD);
+
 /* Device selection for the calling process (one process per GPU): hipSetDevice + probe. */
 int raptor_init(int device);
 

@@ -1457,6 +1457,91 @@ int oracle_constrained_id_eval_host(raptor_problem* pr, const double* Z, int B, 
     ORACLE_CATCH
 }
 
+// Costs/src/{MinimizePower,MinimizeTorque,MinimizeInitialVelocity,MinimizeInitialAcceleration}.cpp
+static void cost_compute(Problem& p, int kind, const double* z, bool deriv, double& f, std::vector<double>& grad) {
+    const int N = p.traj.N, V = p.traj.varLength, Nact = p.traj.Nact;
+    f = 0;
+    grad.assign(V, 0.0);
+    if (kind == RAPTOR_COST_MINIMIZE_POWER || kind == RAPTOR_COST_MINIMIZE_TORQUE) {
+        if (p.cid.dc == nullptr) throw std::invalid_argument("costs: the problem has no ConstrainedInverseDynamics");
+        p.cid.compute(z, deriv);
+        for (int i = 0; i < N; i++) {
+            const VecX& tau = p.cid.tau[i];
+            if (kind == RAPTOR_COST_MINIMIZE_POWER) {  // MinimizePower.cpp:32-54
+                const VecX& v = p.traj.q_d[i];
+                VecX power(Nact);
+                double power_squared = 0;
+                for (int j = 0; j < Nact; j++) {
+                    power[j] = tau[j] * v[j];
+                    power_squared += power[j] * power[j];
+                }
+                if (power_squared > 1e-8) {  // Power::SQUARE_ROOT_THRESHOLD
+                    const double power_norm = std::sqrt(power_squared);
+                    f += power_norm;
+                    if (deriv)
+                        for (int c = 0; c < V; c++) {
+                            double s = 0;
+                            for (int j = 0; j < Nact; j++)
+                                s += (tau[j] * p.traj.pq_d_pz[i](j, c) + v[j] * p.cid.ptau_pz[i](j, c)) * power[j];
+                            grad[c] += s / power_norm;
+                        }
+                }
+            } else {  // MinimizeTorque.cpp:32-50
+                double tau_squared = 0;
+                for (int j = 0; j < Nact; j++) tau_squared += tau[j] * tau[j];
+                const double tau_norm = std::sqrt(tau_squared);
+                f += tau_norm;
+                if (tau_norm > 1e-8 && deriv)
+                    for (int c = 0; c < V; c++) {
+                        double s = 0;
+                        for (int j = 0; j < Nact; j++) s += p.cid.ptau_pz[i](j, c) * tau[j];
+                        grad[c] += s / tau_norm;
+                    }
+            }
+        }
+        f /= N;
+        for (double& g : grad) g /= N;
+    } else if (kind == RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY || kind == RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION) {
+        p.traj.compute(z, deriv);  // MinimizeInitialVelocity.cpp:18-30
+        const bool vel = kind == RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY;
+        const VecX& v0 = vel ? p.traj.q_d[0] : p.traj.q_dd[0];
+        double sq = 0;
+        for (int j = 0; j < Nact; j++) sq += v0[j] * v0[j];
+        const double nrm = std::sqrt(sq);
+        f = nrm;
+        if (nrm > 1e-8 && deriv) {
+            const MatX& P = vel ? p.traj.pq_d_pz[0] : p.traj.pq_dd_pz[0];
+            for (int c = 0; c < V; c++) {
+                double s = 0;
+                for (int j = 0; j < Nact; j++) s += P(j, c) * v0[j];
+                grad[c] = s / nrm;
+            }
+        }
+    } else {
+        throw std::invalid_argument("unknown cost kind");
+    }
+}
+
+int oracle_eval_costs_host(raptor_problem* pr, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD) {
+    ORACLE_TRY
+    if (!pr || (!Z && B > 0) || !kinds || !F) throw std::invalid_argument("null argument");
+    if (B < 0 || num_costs < 0) throw std::invalid_argument("negative size");
+    Problem& p = pr->p;
+    std::vector<double> grad;
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < num_costs; k++) {
+            double f;
+            cost_compute(p, kinds[k], Z + (size_t)b * p.n, GRAD != nullptr, f, grad);
+            F[(size_t)b * num_costs + k] = f;
+            if (GRAD)
+                for (int c = 0; c < p.n; c++) GRAD[((size_t)b * num_costs + k) * p.n + c] = grad[c];
+        }
+    ORACLE_CATCH
+}
+int oracle_eval_costs(raptor_problem* pr, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD, void*) {
+    return oracle_eval_costs_host(pr, Z, B, num_costs, kinds, F, GRAD);
+}
+
 void oracle_problem_destroy(raptor_problem* p) { delete p; }
 
 int oracle_problem_layout(const raptor_problem* pr, int* n, int* m, int* num_blocks, int* block_offsets) {

@@ -25,6 +25,10 @@ TRAJ_BEZIER = 1
 TRAJ_POLYNOMIAL = 2
 EVAL_G = 1
 EVAL_JAC = 2
+COST_MINIMIZE_POWER = 0
+COST_MINIMIZE_TORQUE = 1
+COST_MINIMIZE_INITIAL_VELOCITY = 2
+COST_MINIMIZE_INITIAL_ACCELERATION = 3
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -154,7 +158,7 @@ EXPORTS = [
     "problem_destroy", "problem_layout", "problem_bounds", "problem_tspan", "eval_batch",
     "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
-    "legged_problem_create", "constrained_id_eval_host", "digit_problem_create",
+    "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
 ]
 
 
@@ -188,6 +192,8 @@ class CApi:
         f("legged_problem_create").argtypes = [vp, C.POINTER(LeggedDesc), C.POINTER(vp)]
         f("constrained_id_eval_host").argtypes = [vp, _dp, C.c_int] + [_dp] * 7
         f("digit_problem_create").argtypes = [vp, C.POINTER(DigitDesc), C.POINTER(vp)]
+        f("eval_costs").argtypes = [vp, vp, C.c_int, C.c_int, _ip, vp, vp, vp]
+        f("eval_costs_host").argtypes = [vp, _dp, C.c_int, C.c_int, _ip, _dp, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         self._f = f
@@ -385,6 +391,16 @@ class ProblemHandle:
             self.handle, _ptr(Z), B, _ptr(out["q"]), _ptr(out["v"]), _ptr(out["a"]), _ptr(out["tau"]), _ptr(out["lam"]),
             _ptr(out.get("ptau_pz")), _ptr(out.get("plambda_pz"))))
         return out
+
+    def costs_host(self, Z, kinds, derivatives: bool = True):
+        """Costs::compute members f and grad_f for each cost kind (COST_* constants)."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        kk = np.ascontiguousarray(kinds, dtype=np.int32)
+        F = np.empty((B, len(kk)))
+        GR = np.empty((B, len(kk), self.n)) if derivatives else None
+        self.api.check(self.api.fn("eval_costs_host")(self.handle, _ptr(Z), B, len(kk), kk.ctypes.data_as(_ip), _ptr(F), _ptr(GR)))
+        return F, GR
 
     # -- queries ---------------------------------------------------------------------------
     def bounds(self):

@@ -604,6 +604,68 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(cons
     JAC[w] = val;
 }
 
+// Costs::compute reductions over the N samples of one decision vector, from the per-sample records:
+// one workgroup per (z, cost), one lane per column of z.  MinimizePower.cpp:32-54, MinimizeTorque.cpp:32-50,
+// MinimizeInitialVelocity.cpp:18-30 (the Initial* costs read the first sample's trajectory values).
+__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_cost_kernel(const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
+                                                                   const double* __restrict__ basis, const int n,
+                                                                   const double* __restrict__ core, const int num_costs,
+                                                                   const int* __restrict__ kinds, double* __restrict__ F,
+                                                                   double* __restrict__ GRAD) {
+    const long long b = blockIdx.x / num_costs;
+    const int kc = (int)(blockIdx.x - b * num_costs);
+    const int kind = kinds[kc];
+    const int N = T->N, ni = Q->ni, K = Q->K;
+    const int ndyn = ni * K;
+    for (int c = threadIdx.x; c < n || c == 0; c += RAPTOR_BLOCK) {  // lane 0 also owns f
+        const bool live = c < ndyn;
+        const int t = live ? c / K : 0, k = live ? c - t * K : 0;
+        double f = 0.0, g = 0.0;
+        if (kind == RAPTOR_COST_MINIMIZE_POWER || kind == RAPTOR_COST_MINIMIZE_TORQUE) {
+            for (int i = 0; i < N; i++) {
+                const double* rec = core + (size_t)(b * N + i) * Q->c_stride;
+                const double* Bs = basis + (size_t)(i * 3) * K + k;
+                const double B0 = Bs[0], B1 = Bs[K], B2 = Bs[2 * K];
+                const double* D = rec + Q->c_D + (t * 3) * ni;
+                double sq = 0.0, s = 0.0;
+                for (int j = 0; j < ni; j++) {
+                    const double tau = rec[Q->c_tau + j];
+                    const double ptau = D[j] * B0 + D[ni + j] * B1 + D[2 * ni + j] * B2;
+                    if (kind == RAPTOR_COST_MINIMIZE_POWER) {
+                        const double v = rec[Q->c_v + Q->ind_joint[j]];
+                        const double power = tau * v;
+                        sq += power * power;
+                        s += (tau * ((j == t) ? B1 : 0.0) + v * ptau) * power;
+                    } else {
+                        sq += tau * tau;
+                        s += ptau * tau;
+                    }
+                }
+                const double nrm = sqrt(sq);
+                if (kind == RAPTOR_COST_MINIMIZE_POWER) {
+                    if (sq > 1e-8) { f += nrm; g += s / nrm; }
+                } else {
+                    f += nrm;
+                    if (nrm > 1e-8) g += s / nrm;
+                }
+            }
+            f /= N;
+            g /= N;
+        } else {
+            const bool vel = kind == RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY;
+            const double* rec = core + (size_t)(b * N) * Q->c_stride;
+            const double* r0 = rec + (vel ? Q->c_v : Q->c_a);
+            double sq = 0.0;
+            for (int j = 0; j < ni; j++) sq += r0[Q->ind_joint[j]] * r0[Q->ind_joint[j]];
+            const double nrm = sqrt(sq);
+            f = nrm;
+            if (nrm > 1e-8) g = basis[(vel ? 1 : 2) * K + k] * r0[Q->ind_joint[t]] / nrm;
+        }
+        if (c == 0) F[b * num_costs + kc] = f;
+        if (GRAD != nullptr && c < n) GRAD[((size_t)b * num_costs + kc) * n + c] = live ? g : 0.0;
+    }
+}
+
 // ConstrainedInverseDynamics::ptau_pz / plambda_pz view for the parity entry point: [B][N][rows][n]
 __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_id_kernel(const DevTraj* __restrict__ T,
                                                                         const DevLegged* __restrict__ Q,

@@ -101,6 +101,7 @@ struct raptor_problem {
     bool has_digit = false;
     DevBuf<DevDigit> d_digit;
     DevBuf<double> s_loops;  // per-sample closed-loop records (digit_kernel.h)
+    DevBuf<int> d_kinds;
     DevModel hmodel;
     DevTraj htraj;
     DevSpheres hspheres;
@@ -1051,6 +1052,43 @@ int raptor_inverse_dynamics_eval_host(raptor_problem* p, const double* Z, int B,
     HIP_CHECK(hipDeviceSynchronize());
     if (tau) HIP_CHECK(hipMemcpy(tau, p->s_G.p, (size_t)B * rows * sizeof(double), hipMemcpyDeviceToHost));
     if (ptau_pz) HIP_CHECK(hipMemcpy(ptau_pz, p->s_J.p, (size_t)B * rows * n * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_eval_costs(raptor_problem* p, const double* d_Z, int B, int num_costs, const int* kinds, double* d_F, double* d_GRAD,
+                      void* stream) {
+    API_TRY
+    if (!p || !kinds || (B > 0 && (!d_Z || !d_F))) throw std::invalid_argument("null argument");
+    if (B < 0 || num_costs < 0) throw std::invalid_argument("negative size");
+    if (p->kind != 2) throw std::invalid_argument("costs: the problem has no ConstrainedInverseDynamics");
+    for (int k = 0; k < num_costs; k++)
+        if (kinds[k] < 0 || kinds[k] > RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION) throw std::invalid_argument("unknown cost kind");
+    if (B == 0 || num_costs == 0) return RAPTOR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    launch_legged_core(*p, d_Z, B, nullptr, d_GRAD != nullptr, st);
+    p->d_kinds.ensure(num_costs);
+    HIP_CHECK(hipMemcpyAsync(p->d_kinds.p, kinds, num_costs * sizeof(int), hipMemcpyHostToDevice, st));
+    if ((long long)B * num_costs > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+    hipLaunchKernelGGL(legged_cost_kernel, dim3((unsigned)(B * num_costs)), dim3(RAPTOR_BLOCK), 0, st, p->d_traj.p, p->d_leg.p,
+                       p->d_basis.p, p->layout.n, p->s_core.p, num_costs, p->d_kinds.p, d_F, d_GRAD);
+    HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+int raptor_eval_costs_host(raptor_problem* p, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD) {
+    API_TRY
+    if (!p || !kinds || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
+    if (B < 0 || num_costs < 0) throw std::invalid_argument("negative size");
+    if (B == 0 || num_costs == 0) return RAPTOR_OK;
+    const size_t n = p->layout.n;
+    p->s_Z.upload(Z, (size_t)B * n);
+    p->s_G.ensure((size_t)B * num_costs);
+    if (GRAD) p->s_J.ensure((size_t)B * num_costs * n);
+    const int rc = raptor_eval_costs(p, p->s_Z.p, B, num_costs, kinds, p->s_G.p, GRAD ? p->s_J.p : nullptr, nullptr);
+    if (rc != RAPTOR_OK) return rc;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(F, p->s_G.p, (size_t)B * num_costs * sizeof(double), hipMemcpyDeviceToHost));
+    if (GRAD) HIP_CHECK(hipMemcpy(GRAD, p->s_J.p, (size_t)B * num_costs * n * sizeof(double), hipMemcpyDeviceToHost));
     API_CATCH
 }
 

@@ -423,3 +423,26 @@ def test_digit_full_size_properties(hip):
         kinked[p.block_offsets[2] + 7 * i + 2] = True
     assert err[:, ~kinked].max().item() < 1e-6
     assert (err[:, kinked] < 1e-6).double().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("robot", ["g1", "digit"])
+def test_costs(oracle, hip, robot):
+    """Costs::compute (f, grad_f) of MinimizePower / MinimizeTorque / MinimizeInitialVelocity / MinimizeInitialAcceleration."""
+    keep = []
+    if robot == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=14)
+        ph, _, _ = H.digit_problem(hip, keep, N=14)
+    else:
+        po, m, cfg = H.legged_problem(oracle, robot, keep, N=14)
+        ph, _, _ = H.legged_problem(hip, robot, keep, N=14)
+    rng = np.random.default_rng(20250523 + 6)
+    Z = 0.1 * rng.uniform(-1, 1, (6, po.n))
+    Z[0] = 0.0  # degenerate start: every norm guard (1e-8 thresholds) is hit
+    kinds = [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_INITIAL_VELOCITY, A.COST_MINIMIZE_INITIAL_ACCELERATION, A.COST_MINIMIZE_TORQUE]
+    Fo, Go = po.costs_host(Z, kinds)
+    Fh, Gh = ph.costs_host(Z, kinds)
+    check(Fh, Fo)
+    check(Gh, Go)
+    Fh2, none = ph.costs_host(Z, kinds, derivatives=False)
+    assert none is None
+    check(Fh2, Fo)

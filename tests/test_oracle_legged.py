@@ -105,3 +105,32 @@ def test_digit_layout_bounds_and_errors(oracle):
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, 4, 12, cfg.degree, A.TIME_CHEBYSHEV)
     with pytest.raises(A.RaptorError):
         A.ProblemHandle.digit(oracle, mh, t, cfg)
+
+
+@pytest.mark.parametrize("robot", ["talos", "digit"])
+def test_costs_gradient_finite_differences(oracle, robot):
+    """TestMinimizePowerCosts.cpp:13-78 / TestMinimizeTorqueCosts.cpp:13-76 recipe (central differences, 1e-4)."""
+    from raptor_amd import _capi as A
+
+    keep = []
+    if robot == "digit":
+        p, m, cfg = H.digit_problem(oracle, keep, N=4)
+        ndyn = 72
+    else:
+        p, m, cfg = H.legged_problem(oracle, robot, keep, N=4)
+        ndyn = 84
+    Z = 0.1 * np.random.default_rng(4).uniform(-1, 1, (1, p.n))
+    kinds = [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_TORQUE, A.COST_MINIMIZE_INITIAL_VELOCITY, A.COST_MINIMIZE_INITIAL_ACCELERATION]
+    F, GR = p.costs_host(Z, kinds)
+    assert np.all(F > 0) and np.all(GR[0][:, ndyn:] == 0)
+    h = 1e-6
+    cols = list(range(0, ndyn, 5))
+    for c in cols:
+        zp, zm = Z.copy(), Z.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        fd = (p.costs_host(zp, kinds, False)[0][0] - p.costs_host(zm, kinds, False)[0][0]) / (2 * h)
+        assert np.all(np.abs(fd - GR[0][:, c]) < 1e-4 * (1 + np.abs(GR[0]).max(axis=1))), c
+    # ||q_d(0)|| of an all-zero trajectory: below the square-root threshold the gradient stays zero (:26)
+    F0, G0 = p.costs_host(np.zeros((1, p.n)), kinds[2:])
+    assert np.all(F0 == 0) and np.all(G0 == 0)
