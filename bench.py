@@ -115,6 +115,7 @@ def main() -> None:
     ap.add_argument("--workload", default="kinova", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Digit record appended to the default (Kinova) line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -136,57 +137,56 @@ def main() -> None:
     import raptor_amd
     from raptor_amd import _capi as A
 
-    W = WORKLOADS[args.workload]()
     hip = raptor_amd.api()  # raises if the HIP library is missing: there is no fallback
     hip.init(local_rank)
-    keep = []
-    prob = W.build(hip, keep)
-    B = args.batch or W.batch
-    gen = torch.Generator(device="cpu").manual_seed(20250523 + 1 + rank)
-    Z = (W.z_scale * (torch.rand(B, prob.n, generator=gen, dtype=torch.float64) * 2 - 1)).cuda()
-    G = torch.empty(B, prob.m, dtype=torch.float64, device="cuda")
-    J = torch.empty(B, prob.m, prob.n, dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    flags = A.EVAL_G | A.EVAL_JAC
-
-    def step():
-        prob.eval_device(Z.data_ptr(), B, flags, G.data_ptr(), J.data_ptr(), stream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    prob.profile_begin(args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n_prof, k0_ms, k1_ms = prob.profile_end()
+    def run(W, batch, cpu_seconds):
+        """W over `args.steps` timed steps; returns the JSON record (rank 0) or None."""
+        keep = []
+        prob = W.build(hip, keep)
+        B = batch or W.batch
+        gen = torch.Generator(device="cpu").manual_seed(20250523 + 1 + rank)
+        Z = (W.z_scale * (torch.rand(B, prob.n, generator=gen, dtype=torch.float64) * 2 - 1)).cuda()
+        G = torch.empty(B, prob.m, dtype=torch.float64, device="cuda")
+        J = torch.empty(B, prob.m, prob.n, dtype=torch.float64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        flags = A.EVAL_G | A.EVAL_JAC
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step():
+            prob.eval_device(Z.data_ptr(), B, flags, G.data_ptr(), J.data_ptr(), stream)
 
-    sample_evals = B * W.samples
-    value = world * sample_evals * args.steps / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
-
-    if rank == 0:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        prob.profile_begin(args.steps)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        n_prof, k0_ms, k1_ms = prob.profile_end()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank != 0:
+            return None
+        sample_evals = B * W.samples
         assert bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all())
         kms = [k0_ms, k1_ms]
         dom_ms = kms[W.dominant]
         dom_s = dom_ms * 1e-3
         tot_s = (k0_ms + k1_ms) * 1e-3
         alg_bytes = sample_evals * W.bytes_per_se
+        ms_per_step = 1e3 * elapsed / args.steps
         out = {
             "metric": "RNEA+dtau/dz sample-evals/sec (fp64)",
-            "value": value,
+            "value": world * sample_evals * args.steps / elapsed,
             "unit": "sample-evals/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -210,7 +210,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (alg_bytes / dom_s / 1e9) / HBM_PEAK_GBS if dom_s > 0 else None,
-                "traffic": pmc_traffic(W.pmc_key),
+                "traffic": pmc_traffic(W.pmc_key, W.name),
                 "kernel_ms": dom_ms,
                 "launches_timed": n_prof,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -226,20 +226,29 @@ def main() -> None:
             },
             "kernels_ms": {k: v for k, v in zip(W.kernels, kms) if k},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), args.cpu_seconds, G, J)
+        if world == 1 and cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), cpu_seconds, G, J)
+        return out
+
+    out = run(WORKLOADS[args.workload](), args.batch, 0.0 if args.no_cpu_baseline else args.cpu_seconds)
+    if args.workload == "kinova" and not args.no_secondary:
+        # the north-star target is quoted on Digit-v3 (BASELINE.json): measure it in the same run, as a secondary record
+        sec = run(WORKLOADS["digit"](), 0, 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 6.0))
+        if out is not None:
+            out["secondary"] = {"digit": {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels_ms", "cpu_baseline") if k in sec}}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(key):
+def pmc_traffic(key, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
     collected with this same command in separate WRITE_SIZE / FETCH_SIZE runs); None when no such entry is present."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        k = d[key]
+        k = d.get(workload + ":" + key) or d[key]
         return k["WRITE_SIZE_bytes"] + k["FETCH_SIZE_bytes"]
     except Exception:
         return None
