@@ -31,15 +31,14 @@
 
 #define LEG_BLOCK 64      // core kernel: one wavefront per workgroup (no workgroup barrier anywhere)
 #define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
+#define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
 template <int LG>
 struct LegLds {
-    static constexpr int X = 0;                 // phase-0 exchange: qd, qdd, cos q, sin q, q per body
-    static constexpr int V = LG * 5;            // per-joint vectors
-    static constexpr int W = V + LG * LEG_VEC;  // chain-rule weights: 2 slots x (G, Hv, Hq) per joint
-    static constexpr int TT = W + LG * 6;       // tree-joint torques
-    static constexpr int TS = TT + LG;          // per-column scratch: T_q, T_v, T_a per joint
-    static constexpr int STRIDE = TS + LG * 3 + 2;
+    // phases 0/A: per-joint local transform (LEG_LOC doubles) ; phases E/F: per-joint 6-vectors (LEG_VEC doubles) -- same area
+    static constexpr int V = 0;
+    static constexpr int TS = LG * LEG_VEC;     // per-column scratch: T_q, T_v, T_a per joint
+    static constexpr int STRIDE = TS + LG * 3 + 2;  // LG = 32: 1250 doubles -> 2 sample-evals = 20 KB per wavefront, 8 waves per CU
 };
 
 // Utils::wrapToPi (Utils/include/Utils.h:59-68)
@@ -99,7 +98,7 @@ RD double contact_row(int r, const double* lam, const double* p, double mu, doub
 }
 
 template <int LG, bool DERIV>
-__global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
+__global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
     const double* __restrict__ loops, double* __restrict__ G, double* __restrict__ core) {
@@ -150,12 +149,36 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
         w1[2] = lr[4] * xdda + lr[5] * xddb + lr[7] * xda * xda + 2.0 * lr[8] * xda * xdb + lr[9] * xdb * xdb;
     }
     if (has_joint) {
+        // local transform across this joint in the direction of the walk (foot -> this body), so that the walk below is
+        // branch free:  forward joint  R' = R (plR Rq),  o' = o + R plp,         axis = R (plR e),   joint origin o'
+        //               reversed joint R' = R (plR Rq)^T, o' = o - R' plp,       axis = -R e,        joint origin o
         sincos(q, &sq, &cq);
-        double* x = sl + LL::X + g * 5;
-        x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
-        double* ww = sl + LL::W + g * 6;
-        ww[0] = w0[0]; ww[1] = w0[1]; ww[2] = w0[2];
-        ww[3] = w1[0]; ww[4] = w1[1]; ww[5] = w1[2];
+        M3 P;
+#pragma unroll
+        for (int k = 0; k < 9; k++) P.m[k] = M->plR[jnt][k];
+        const V3 pl = v3(M->plp[jnt][0], M->plp[jnt][1], M->plp[jnt][2]);
+        M3 X;
+        V3 dummy = v3(0, 0, 0);
+        SV sj;
+        joint_world(M->jtype[jnt], q, cq, sq, P, X, dummy, sj);  // X = plR Rq(q), sj.a = signed axis in the parent link frame
+        const bool rev = Q->body_rev[gb] != 0;
+        V3 t = pl, ax = sj.a;
+        if (rev) {
+            M3 Xt;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Xt.m[3 * r + c] = X.m[3 * c + r];
+            X = Xt;
+            t = -mul(X, pl);
+            ax = -mul(X, sj.a);
+        }
+        double* x = sl + LL::V + g * LEG_LOC;
+#pragma unroll
+        for (int k = 0; k < 9; k++) x[k] = X.m[k];
+        x[9] = t.x; x[10] = t.y; x[11] = t.z;
+        x[12] = ax.x; x[13] = ax.y; x[14] = ax.z;
+        x[15] = qd; x[16] = qdd; x[17] = rev ? 1.0 : 0.0;
     }
     wave_sync();
 
@@ -171,29 +194,15 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     const int depth = has_body ? Q->body_depth[gb] : 0;
 #pragma unroll 1
     for (int d = 0; d < depth; d++) {
-        const int l = Q->path[gb][d];
-        const int j = Q->body_joint[l];
-        const double* x = sl + LL::X + l * 5;
-        const double lqd = x[0], lqdd = x[1], lcq = x[2], lsq = x[3], lq = x[4];
-        const int jt = M->jtype[j];
-        const V3 pl = v3(M->plp[j][0], M->plp[j][1], M->plp[j][2]);
-        M3 R;
-        V3 o;
-        if (!Q->body_rev[l]) {
-            const M3 A = mul(Rw, M->plR[j]);
-            o = ow + mul(Rw, pl);
-            joint_world(jt, lq, lcq, lsq, A, R, o, s);
-        } else {  // crossing the joint from its child link to its parent link: undo the joint, then the placement
-            M3 A;
-            V3 oj = ow;
-            joint_world(jt, -lq, lcq, -lsq, Rw, A, oj, s);
-            s = s * -1.0;  // the generalized coordinate keeps its meaning, the successor body is on the other side
-            R = mulBT(A, M->plR[j]);
-            o = oj - mul(R, pl);
-        }
-        const SV sqd = s * lqd;
+        const double* x = sl + LL::V + Q->path[gb][d] * LEG_LOC;
+        const M3 R = mul(Rw, x);
+        const V3 o = ow + mul(Rw, v3(x[9], x[10], x[11]));
+        const V3 axw = mul(Rw, v3(x[12], x[13], x[14]));
+        const V3 oj = (x[17] != 0.0) ? ow : o;
+        s = SV{axw, cross(oj, axw)};
+        const SV sqd = s * x[15];
         vprev = v;
-        a = a + s * lqdd + crm(v, sqd);
+        a = a + s * x[16] + crm(v, sqd);
         v = v + sqd;
         Rw = R;
         ow = o;
@@ -269,25 +278,32 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     // ---- phase D: values.  tau rows, q rows, contact rows; the same numbers go to the compact record ----
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
+    // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
+    const double tt = has_joint ? dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd : 0.0;
     if (has_joint) {
-        // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
-        sl[LL::TT + g] = dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd;
         rec[Q->c_q + jnt] = q;
         rec[Q->c_v + jnt] = qd;
         rec[Q->c_a + jnt] = qdd;
         if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);  // ConstrainedJointLimits.cpp:57
     }
-    wave_sync();
+    // an actuator's lane collects, from the lanes of the closed-loop joints it drives, their G = Y1 entry and torque
     const int myslot = (tj >= 0) ? Q->ind_slot[tj] : 0;
     const int ndep = (tj >= 0) ? Q->ind_ndep[tj] : 0;
+    double gdep[6], tdep[6];
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+        const int db = (d < ndep) ? Q->ind_dep_body[tj][d] : 0;
+        const double ga = __shfl(w0[0], db, LG), gb_ = __shfl(w1[0], db, LG);
+        const double td = __shfl(tt, db, LG);
+        gdep[d] = (d < ndep) ? (myslot ? gb_ : ga) : 0.0;
+        tdep[d] = (d < ndep) ? td : 0.0;
+    }
     if (tj >= 0) {
         // actuated torque = G^T tau_tree: own joint plus the closed-loop joints this actuator drives
         // (== tau_indep - J_indep^T lambda, ConstrainedInverseDynamics.cpp:175)
-        double tau = sl[LL::TT + g];
-        for (int d = 0; d < ndep; d++) {
-            const int db = Q->ind_dep_body[tj][d];
-            tau += sl[LL::W + db * 6 + myslot * 3] * sl[LL::TT + db];
-        }
+        double tau = tt;
+#pragma unroll
+        for (int d = 0; d < 6; d++) tau += gdep[d] * tdep[d];
         rec[Q->c_tau + tj] = tau;
         if (G != nullptr) G[rowbase + Q->off_tau + (size_t)i * ni + tj] = tau;  // TorqueLimits.cpp:30-34
     }
@@ -361,12 +377,14 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
     }
     // (dG^T/dq) tau_tree: an actuator's torque also changes because the loop Jacobian Y1 moves with the drivers
     double Kq[2] = {0.0, 0.0};
-    for (int d = 0; d < ndep; d++) {
-        const int db = Q->ind_dep_body[tj][d];
-        const double* ld = loops + ((size_t)e * Q->nrec + Q->body_rec[db]) * 10;
-        const double td = sl[LL::TT + db];
-        Kq[0] += ld[3 + myslot] * td;
-        Kq[1] += ld[4 + myslot] * td;
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+        if (d < ndep) {
+            const int db = Q->ind_dep_body[tj][d];
+            const double* ld = loops + ((size_t)e * Q->nrec + Q->body_rec[db]) * 10;
+            Kq[0] += ld[3 + myslot] * tdep[d];
+            Kq[1] += ld[4 + myslot] * tdep[d];
+        }
     }
     const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
     if (rc >= 0) {  // P_dep rows of the closed-loop joints (= Y1, DigitDynamicsConstraints.cpp:394)
@@ -386,8 +404,9 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
             const int k = Q->col_supp_body[it][r];
             const int kend = Q->body_end[k];
             const double* vk = sl + LL::V + k * LEG_VEC;
-            const double* wk = sl + LL::W + k * 6 + Q->col_supp_slot[it][r] * 3;
-            const double g0 = wk[0], hv = wk[1], hq = wk[2];
+            const bool s1 = Q->col_supp_slot[it][r] != 0;  // uniform
+            const double g0 = __shfl(s1 ? w1[0] : w0[0], k, LG), hv = __shfl(s1 ? w1[1] : w0[1], k, LG),
+                         hq = __shfl(s1 ? w1[2] : w0[2], k, LG);
             if (has_joint) {
                 double dq = 0.0, dv = 0.0, da = 0.0;
                 if (k > g && k < gend) {  // this joint is a strict ancestor of k
@@ -443,11 +462,12 @@ __global__ __launch_bounds__(LEG_BLOCK) void legged_core_kernel(
         wave_sync();
         if (tj >= 0) {  // project the rows: G^T
             double Rq = Tq, Rv = Tv, Ra = Ta;
-            for (int d = 0; d < ndep; d++) {
-                const int db = Q->ind_dep_body[tj][d];
-                const double gd = sl[LL::W + db * 6 + myslot * 3];
-                const double* ts = sl + LL::TS + db * 3;
-                Rq += gd * ts[0]; Rv += gd * ts[1]; Ra += gd * ts[2];
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                if (d < ndep) {
+                    const double* ts = sl + LL::TS + Q->ind_dep_body[tj][d] * 3;
+                    Rq += gdep[d] * ts[0]; Rv += gdep[d] * ts[1]; Ra += gdep[d] * ts[2];
+                }
             }
             if (it == lc0) Rq += Kq[0];
             if (it == lc1) Rq += Kq[1];
