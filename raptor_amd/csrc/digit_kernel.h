@@ -325,11 +325,12 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
     S.L = L;
     double Jm[NY][NY + NX];
     LU<NY> lu;
-    // Newton (stands in for gsl_multiroot_fdfsolver_hybridsj, :344-367: same root, residual test sum|c| < 1e-14, <= 50 its)
+    // Newton (stands in for gsl_multiroot_fdfsolver_hybridsj, :344-367: same root; like the reference at least one step,
+    // residual test sum|c| < 1e-14 after a step, at most 50 steps).  Geometry, Jacobian and LU of the accepted point are
+    // reused by the derivative phase below.
     int iter = 0;
 #pragma unroll 1
-    do {
-        iter++;
+    while (true) {
         double c[NY];
         S.geometry(th);
         S.residual(c);
@@ -339,30 +340,16 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
 #pragma unroll
             for (int k = 0; k < NY; k++) lu.a[r][k] = Jm[r][k];
         lu_factor<NY>(lu);
-        lu_solve<NY>(lu, c);
-        double step = 0.0;
-#pragma unroll
-        for (int r = 0; r < NY; r++) {
-            th[r] -= c[r];
-            step += fabs(c[r]);
-        }
-        if (!(step == step)) break;  // singular loop Jacobian: NaNs flow to the outputs
-        S.geometry(th);
-        S.residual(c);
         double res = 0.0;
 #pragma unroll
         for (int r = 0; r < NY; r++) res += fabs(c[r]);
-        if (res < 1e-14) break;
-    } while (iter < 50);
+        if ((iter > 0 && res < 1e-14) || iter >= 50 || !(res == res)) break;  // NaN: singular loop Jacobian, flows to the outputs
+        lu_solve<NY>(lu, c);
+#pragma unroll
+        for (int r = 0; r < NY; r++) th[r] -= c[r];
+        iter++;
+    }
 
-    // derivatives at the solution
-    S.geometry(th);
-    S.jacobian(Jm);
-#pragma unroll
-    for (int r = 0; r < NY; r++)
-#pragma unroll
-        for (int k = 0; k < NY; k++) lu.a[r][k] = Jm[r][k];
-    lu_factor<NY>(lu);
     double Y1[NX][NY], U[NX][NY + NX];
 #pragma unroll
     for (int a = 0; a < NX; a++) {
