@@ -96,12 +96,29 @@ typedef struct raptor_kinova_desc {
 } raptor_kinova_desc;
 
 /*
+ * The robot-specific "customized" kinematic block (swing-foot and torso rows):
+ *   DigitCustomizedConstraints  Examples/Digit/src/DigitCustomizedConstraints.cpp:35-200   (N*10 + 4 rows)
+ *   TalosCustomizedConstraints  Examples/Talos/src/TalosCustomizedConstraints.cpp:35-200   (N*11 + 2 rows; G1 twin)
+ * `enabled == 0` leaves the block out.  The fields are the reference's GaitParameters plus the constants its two
+ * variants differ in.
+ */
+typedef struct raptor_gait_desc {
+    int enabled;
+    int swing_joint_id;             /* model.getJointId(swing foot name), Pinocchio id (1-based); Digit: derived, ignored */
+    double swingfoot_endT_p[3];     /* Talos / G1: leftfoot_endT.p == rightfoot_endT.p; Digit: compiled in              */
+    double eps_torso_angle;
+    double swingfoot_midstep_z_des;
+    double swingfoot_begin_x_des, swingfoot_begin_y_des, swingfoot_end_x_des, swingfoot_end_y_des;
+    double torso_height_lb;         /* 0.95 Talos, 0.55 G1 (g6_lb); Digit: 1.05 compiled in, ignored                     */
+} raptor_gait_desc;
+
+/*
  * Floating-base robot whose six base joints are made dependent by a planted stance foot: the arguments of
  * TalosSingleStepOptimizer::set_parameters / G1SingleStepOptimizer::set_parameters that reach the hot path
  * (Examples/Talos/src/TalosSingleStepOptimizer.cpp:17-124, TalosDynamicsConstraints.cpp:6-42, same for Unitree-G1).
- * Blocks built: [torque limits N*Nact | joint limits N*nv | contact N*7]
- * (TorqueLimits, ConstrainedJointLimits, RectangleSurfaceContactConstraints; the robot-specific "customized" and
- * periodicity blocks are not built yet).
+ * Blocks built: [torque limits N*Nact | joint limits N*nv | contact N*7 | customized N*11 + 2 (optional)]
+ * (TorqueLimits, ConstrainedJointLimits, RectangleSurfaceContactConstraints, *CustomizedConstraints; the periodicity
+ * block is not built yet).
  */
 typedef struct raptor_legged_desc {
     raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = num_independent                                 */
@@ -120,6 +137,8 @@ typedef struct raptor_legged_desc {
     const double* joint_limits_lower;  /* [nv] */
     const double* joint_limits_upper;
     double mu, gamma, Lx, Ly;       /* rectangleContactSurfaceParams(MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH)           */
+    int stance_leg;                 /* 'L' or 'R' (only the customized block reads it)                             */
+    raptor_gait_desc gait;          /* fourth block: TalosCustomizedConstraints / G1CustomizedConstraints          */
 } raptor_legged_desc;
 
 /*
@@ -128,7 +147,7 @@ typedef struct raptor_legged_desc {
  * (Examples/Digit/include/DigitDynamicsConstraints.h:19-57).  The closed-loop constants (rod / anchor end points,
  * stance-foot end transform, initial-guess fit) are compiled in, as the reference hard-codes them
  * (DigitDynamicsConstraints.h:178-198, DigitDynamicsConstraints.cpp:255-314).
- * Blocks built: [torque limits N*12 | joint limits N*36 | contact N*7].
+ * Blocks built: [torque limits N*12 | joint limits N*36 | contact N*7 | customized N*10 + 4 (optional)].
  */
 typedef struct raptor_digit_desc {
     raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = 12                                               */
@@ -144,6 +163,7 @@ typedef struct raptor_digit_desc {
     const double* joint_limits_lower;  /* [36] radians */
     const double* joint_limits_upper;
     double mu, gamma, Lx, Ly;
+    raptor_gait_desc gait;          /* fourth block: DigitCustomizedConstraints                                    */
 } raptor_digit_desc;
 
 typedef struct raptor_model raptor_model;     /* opaque */

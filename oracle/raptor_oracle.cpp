@@ -1318,6 +1318,13 @@ int oracle_legged_problem_create(const raptor_model* model, const raptor_legged_
     p.cons.emplace_back(new ConstrainedTorqueLimits(&p.cid, tl, tu));                                   // TalosSingleStepOptimizer.cpp:69-73
     p.cons.emplace_back(new ConstrainedJointLimits(&p.cid, jl, ju));                                    // :82-86
     p.cons.emplace_back(new RectangleSurfaceContactConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly)); // :89-92
+    if (d->gait.enabled) {  // :95-99
+        if (d->stance_leg != 'L' && d->stance_leg != 'R') throw std::runtime_error("Invalid stance leg input");
+        if (d->gait.swing_joint_id < 1 || d->gait.swing_joint_id > nv) throw std::runtime_error("Can not find joint");
+        p.cons.emplace_back(new CustomizedConstraints(
+            &p.cid, false, d->stance_leg == 'L', d->gait.swing_joint_id,
+            Transform(Vec3(d->gait.swingfoot_endT_p[0], d->gait.swingfoot_endT_p[1], d->gait.swingfoot_endT_p[2])), d->gait));
+    }
     p.finish();
     *out = pr.release();
     ORACLE_CATCH
@@ -1420,6 +1427,15 @@ int oracle_digit_problem_create(const raptor_model* model, const raptor_digit_de
     p.cons.emplace_back(new ConstrainedTorqueLimits(&p.cid, tl, tu));                                   // DigitSingleStepOptimizer.cpp:74-79
     p.cons.emplace_back(new ConstrainedJointLimits(&p.cid, jl, ju));                                    // :82-87
     p.cons.emplace_back(new RectangleSurfaceContactConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly)); // :90-94
+    if (d->gait.enabled) {  // :97-101
+        double R[9], pp[3];
+        digit_stance_foot_endT(1 - sleg, R, pp);  // the swing foot's end transform (DigitCustomizedConstraints.cpp:16-24)
+        Mat3 Re;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Re(r, c) = R[3 * r + c];
+        p.cons.emplace_back(new CustomizedConstraints(&p.cid, true, sleg == 0, d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1,
+                                                      Transform(Re, Vec3(pp[0], pp[1], pp[2])), d->gait));
+    }
     p.finish();
     *out = pr.release();
     ORACLE_CATCH

@@ -80,6 +80,35 @@ class KinovaDesc(C.Structure):
     ]
 
 
+class GaitDesc(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int),
+        ("swing_joint_id", C.c_int),
+        ("swingfoot_endT_p", C.c_double * 3),
+        ("eps_torso_angle", C.c_double),
+        ("swingfoot_midstep_z_des", C.c_double),
+        ("swingfoot_begin_x_des", C.c_double),
+        ("swingfoot_begin_y_des", C.c_double),
+        ("swingfoot_end_x_des", C.c_double),
+        ("swingfoot_end_y_des", C.c_double),
+        ("torso_height_lb", C.c_double),
+    ]
+
+
+def _gait(cfg) -> "GaitDesc":
+    g = GaitDesc()
+    gp = getattr(cfg, "gait", None)
+    if gp is None:
+        return g
+    g.enabled = 1
+    g.swing_joint_id = int(gp.get("swing_joint_id", 0))
+    g.swingfoot_endT_p = (C.c_double * 3)(*[float(x) for x in gp.get("swingfoot_endT_p", (0, 0, 0))])
+    for k in ("eps_torso_angle", "swingfoot_midstep_z_des", "swingfoot_begin_x_des", "swingfoot_begin_y_des",
+              "swingfoot_end_x_des", "swingfoot_end_y_des", "torso_height_lb"):
+        setattr(g, k, float(gp.get(k, 0.0)))
+    return g
+
+
 class LeggedDesc(C.Structure):
     _fields_ = [
         ("traj", TrajDesc),
@@ -101,6 +130,8 @@ class LeggedDesc(C.Structure):
         ("gamma", C.c_double),
         ("Lx", C.c_double),
         ("Ly", C.c_double),
+        ("stance_leg", C.c_int),
+        ("gait", GaitDesc),
     ]
 
 
@@ -121,6 +152,7 @@ class DigitDesc(C.Structure):
         ("gamma", C.c_double),
         ("Lx", C.c_double),
         ("Ly", C.c_double),
+        ("gait", GaitDesc),
     ]
 
 
@@ -351,6 +383,8 @@ class ProblemHandle:
         d.torque_limits_lower, d.torque_limits_upper = _ptr(tl), _ptr(tu)
         d.joint_limits_lower, d.joint_limits_upper = _ptr(jl), _ptr(ju)
         d.mu, d.gamma, d.Lx, d.Ly = float(cfg.mu), float(cfg.gamma), float(cfg.Lx), float(cfg.Ly)
+        d.stance_leg = ord(getattr(cfg, "stance_leg", "L"))
+        d.gait = _gait(cfg)
         h = C.c_void_p()
         api.check(api.fn("legged_problem_create")(model.handle, C.byref(d), C.byref(h)))
         return cls(api, h)
@@ -373,6 +407,7 @@ class ProblemHandle:
         d.torque_limits_lower, d.torque_limits_upper = _ptr(tl), _ptr(tu)
         d.joint_limits_lower, d.joint_limits_upper = _ptr(jl), _ptr(ju)
         d.mu, d.gamma, d.Lx, d.Ly = float(cfg.mu), float(cfg.gamma), float(cfg.Lx), float(cfg.Ly)
+        d.gait = _gait(cfg)
         h = C.c_void_p()
         api.check(api.fn("digit_problem_create")(model.handle, C.byref(d), C.byref(h)))
         return cls(api, h)

@@ -94,11 +94,23 @@ struct DevLegged {
     int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)
     int ind_loop_col[RAPTOR_LEG_MAX_IND][2];  // minimal columns of the drivers (a, b) of t's loop, -1: none
     int dep_col[RAPTOR_MAX_NV][2];            // by dependent index (>= 6): minimal columns of its two P_dep entries
+    // robot-specific "customized" block (swing-foot / torso rows): rows are linear in 12 pose quantities of ONE sample,
+    // X[0..5] = swing-foot x y z roll pitch yaw, X[6..11] = floating-base coordinates q[0..5]
+    int ncust, off_cust;                      // rows (0: block absent), offset in Optimizer row order
+    int sf_body;                              // body that carries the swing foot
+    double sf_R[9], sf_p[3];                  // swing-foot end transform
     int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
     // per-sample-eval record written by the core kernel (doubles):
     //   tau[ni] lambda[6] q[nv] v[nv] a[nv] | D[it][x][ni] (x = q, v, a; rows = actuators) | L[it][x][6] |
     //   Pb[it][6] (floating-base rows of P_dep) | Pl[nd - 6][2] (closed-loop rows of P_dep, columns dep_col)
-    int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_Pl, c_stride;
+    //   sf[6] swing-foot x y z roll pitch yaw | Psf[it][6] its derivative per unit actuator displacement
+    int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_Pl, c_sf, c_Psf, c_stride;
+};
+
+// one row of the customized block: g = wrap?( ca * X[qa] + cb * X[qb] + add ), X of sample `sample`
+struct DevCustRow {
+    int sample, qa, qb, wrap;
+    double ca, cb, add;
 };
 
 // where each constraint block of this problem starts in the Optimizer's row order (-1: block absent)

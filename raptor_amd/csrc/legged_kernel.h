@@ -101,7 +101,8 @@ template <int LG, bool DERIV>
 __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
-    const double* __restrict__ loops, double* __restrict__ G, double* __restrict__ core) {
+    const double* __restrict__ loops, const DevCustRow* __restrict__ cust, const int* __restrict__ cust_list,
+    const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core) {
     extern __shared__ double lds[];
     using LL = LegLds<LG>;
     constexpr int EPB = LEG_BLOCK / LG;
@@ -352,6 +353,42 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + dj] = wrap_to_pi(qv[k]);
         }
     }
+    // customized block (DigitCustomizedConstraints.cpp:88-125 / TalosCustomizedConstraints.cpp:88-124): the swing foot's
+    // lane evaluates this sample's rows from its own pose and the floating-base coordinates of the torso's lane
+    const bool is_sf = Q->ncust > 0 && has_body && g == Q->sf_body;
+    M3 Rsf;
+    V3 psf = v3(0, 0, 0);
+    if (Q->ncust > 0) {
+        double X[12];
+        {
+            const V3 rpy_t = v3(atan2(-Rw.m[5], Rw.m[8]), safe_asin(Rw.m[2]), atan2(-Rw.m[1], Rw.m[0]));
+            const double mine[6] = {ow.x, ow.y, ow.z, rpy_t.x, rpy_t.y, rpy_t.z};
+#pragma unroll
+            for (int k = 0; k < 6; k++) X[6 + k] = __shfl(mine[k], Q->torso_body, LG);
+        }
+        if (is_sf) {
+            Rsf = mul(Rw, Q->sf_R);
+            psf = ow + mul(Rw, v3(Q->sf_p[0], Q->sf_p[1], Q->sf_p[2]));
+            X[0] = psf.x; X[1] = psf.y; X[2] = psf.z;
+            X[3] = atan2(-Rsf.m[5], Rsf.m[8]); X[4] = safe_asin(Rsf.m[2]); X[5] = atan2(-Rsf.m[1], Rsf.m[0]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) rec[Q->c_sf + k] = X[k];
+            if (G != nullptr) {
+                for (int rr = cust_start[i]; rr < cust_start[i + 1]; rr++) {
+                    const int row = cust_list[rr];
+                    const DevCustRow cr = cust[row];
+                    double xa = 0.0, xb = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        xa = (k == cr.qa) ? X[k] : xa;
+                        xb = (k == cr.qb) ? X[k] : xb;
+                    }
+                    const double val = cr.ca * xa + cr.cb * xb + cr.add;
+                    G[rowbase + Q->off_cust + row] = cr.wrap ? wrap_to_pi(val) : val;
+                }
+            }
+        }
+    }
     if (!DERIV) return;
 
     // ---- phase E: per-joint 6-vectors of the analytic derivative ----
@@ -433,7 +470,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 Fv = Fv + cvk * g0 + ISk * hv;
                 Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
             }
-            if (is_torso && g >= k && g < kend) tw = tw + lds_sv(vk) * g0;  // torso twist per unit rate of `it`
+            if ((is_torso || is_sf) && g >= k && g < kend) tw = tw + lds_sv(vk) * g0;  // body twist per unit rate of `it`
         }
         if (has_joint) {
             double* ts = sl + LL::TS + g * 3;
@@ -458,6 +495,13 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
             for (int k = 0; k < 6; k++) rec[Q->c_P + it * 6 + k] = pc[k];
+        }
+        if (is_sf) {  // swing-foot pose derivative (translation / RPY Jacobian times pq_pz, DigitCustomizedConstraints.cpp:80-82)
+            const V3 lin = tw.l + cross(tw.a, psf);
+            const V3 rot = rpy_rates(Rsf, tw.a);
+            const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
+#pragma unroll
+            for (int k = 0; k < 6; k++) rec[Q->c_Psf + it * 6 + k] = pc[k];
         }
         wave_sync();
         if (tj >= 0) {  // project the rows: G^T
@@ -538,10 +582,46 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
     }
 }
 
+// customized rows of one sample: scattered rows (the block is ordered by quantity, then by sample), each n doubles
+RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int nrows, const int* __restrict__ list,
+                           const DevCustRow* __restrict__ cust, double* __restrict__ blockbase, const double* __restrict__ rec,
+                           const double* __restrict__ wB, const int* __restrict__ tcol, const DevLegged* __restrict__ Q) {
+    const double* Pb = rec + Q->c_P;
+    const double* Ps = rec + Q->c_Psf;
+    const int dr = (2 * RAPTOR_BLOCK) / n, dc = (2 * RAPTOR_BLOCK) - dr * n;
+    const int total = nrows * n;
+    int el = 2 * tid;
+    int r = el / n, c = el - r * n;
+    for (; el < total; el += 2 * RAPTOR_BLOCK) {
+        const int row = list[r];
+        const DevCustRow cr = cust[row];
+        double o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cc = c + h;
+            double val = 0.0;
+            if (cc < ndyn) {
+                const int t = tcol[cc];
+                const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
+                const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
+                val = (cr.ca * da + cr.cb * db) * wB[cc];
+            }
+            o[h] = val;
+        }
+        *reinterpret_cast<double2*>(blockbase + (size_t)row * n + c) = make_double2(o[0], o[1]);
+        r += dr;
+        c += dc;
+        if (c >= n) { c -= n; r++; }
+    }
+}
+
 __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTraj* __restrict__ T,
                                                                      const DevLegged* __restrict__ Q,
                                                                      const double* __restrict__ basis, const DevLayout L,
                                                                      const double* __restrict__ core,
+                                                                     const DevCustRow* __restrict__ cust,
+                                                                     const int* __restrict__ cust_list,
+                                                                     const int* __restrict__ cust_start,
                                                                      double* __restrict__ JAC) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
@@ -577,13 +657,17 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTr
     legged_expand_piece<0>(tid, n, ndyn, ni, ni, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, wB, tcol, rowinfo, Q);
     legged_expand_piece<1>(tid, n, ndyn, ni, nv, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, wB, tcol, rowinfo, Q);
     legged_expand_piece<2>(tid, n, ndyn, ni, 7, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, wB, tcol, rowinfo, Q);
+    if (Q->ncust > 0)
+        legged_expand_cust(tid, n, ndyn, cust_start[i + 1] - cust_start[i], cust_list + cust_start[i], cust,
+                           base + (size_t)Q->off_cust * n, rec, wB, tcol, Q);
 }
 
 // fallback for an odd number of columns: one entry per lane
 __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(const DevTraj* __restrict__ T,
                                                                             const DevLegged* __restrict__ Q,
                                                                             const double* __restrict__ basis, const DevLayout L,
-                                                                            const double* __restrict__ core, const long long total,
+                                                                            const double* __restrict__ core,
+                                                                            const DevCustRow* __restrict__ cust, const long long total,
                                                                             double* __restrict__ JAC) {
     const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
     if (w >= total) return;
@@ -596,7 +680,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(cons
     if (c < ni * K) {
         const int t = c / K, k = c - t * K;
         int i, lr, piece;
-        if (r >= Q->off_tau && r < Q->off_tau + N * ni) { piece = 0; i = (r - Q->off_tau) / ni; lr = (r - Q->off_tau) - i * ni; }
+        if (Q->ncust > 0 && r >= Q->off_cust && r < Q->off_cust + Q->ncust) { piece = 3; lr = r - Q->off_cust; i = cust[lr].sample; }
+        else if (r >= Q->off_tau && r < Q->off_tau + N * ni) { piece = 0; i = (r - Q->off_tau) / ni; lr = (r - Q->off_tau) - i * ni; }
         else if (r >= Q->off_q && r < Q->off_q + N * nv) { piece = 1; i = (r - Q->off_q) / nv; lr = (r - Q->off_q) - i * nv; }
         else { piece = 2; i = (r - Q->off_contact) / 7; lr = (r - Q->off_contact) - i * 7; }
         const double* Bs = basis + (size_t)(i * 3) * K + k;
@@ -613,6 +698,13 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(cons
                 if (dd < 6) val = rec[Q->c_P + t * 6 + dd] * B0;
                 else val = ((t == Q->dep_col[dd][0]) ? rec[Q->c_Pl + (dd - 6) * 2] : ((t == Q->dep_col[dd][1]) ? rec[Q->c_Pl + (dd - 6) * 2 + 1] : 0.0)) * B0;
             }
+        } else if (piece == 3) {
+            const DevCustRow cr = cust[lr];
+            const double* Pb = rec + Q->c_P;
+            const double* Ps = rec + Q->c_Psf;
+            const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
+            const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
+            val = (cr.ca * da + cr.cb * db) * B0;
         } else {
             double p[6];
             const double* l = rec + Q->c_L + (t * 3) * 6;

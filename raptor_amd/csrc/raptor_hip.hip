@@ -102,6 +102,8 @@ struct raptor_problem {
     DevBuf<DevDigit> d_digit;
     DevBuf<double> s_loops;  // per-sample closed-loop records (digit_kernel.h)
     DevBuf<int> d_kinds;
+    DevBuf<DevCustRow> d_cust;       // customized block: row specs by row, per-sample row lists
+    DevBuf<int> d_cust_list, d_cust_start;
     DevModel hmodel;
     DevTraj htraj;
     DevSpheres hspheres;
@@ -329,7 +331,8 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const unsigned grid = (unsigned)((E + epb - 1) / epb);
 #define LEG_LAUNCH(LGV, DV)                                                                                          \
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
-                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, dG, p.s_core.p)
+                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
+                       p.d_cust_start.p, dG, p.s_core.p)
     if (wide) {
         if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
     } else {
@@ -350,12 +353,12 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         const int ndyn = p.hleg.ni * p.hleg.K;
         const size_t lds_bytes = (size_t)(p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
         hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)E), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_leg.p,
-                           p.d_basis.p, p.layout, p.s_core.p, dJ);
+                           p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, dJ);
     } else {
         const long long total = (long long)B * p.layout.m * p.layout.n;
         if (total / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
         hipLaunchKernelGGL(legged_expand_scalar_kernel, dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_leg.p,
-                           p.d_basis.p, p.layout, p.s_core.p, total, dJ);
+                           p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, total, dJ);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -572,6 +575,11 @@ struct LeggedSetup {
     // closed loops: for a dependent joint that is not part of the floating base, its record and its driving joints
     std::vector<int> loop_rec, loop_drv_a, loop_drv_b;  // indexed by model joint, -1: none
     int nrec = 0;
+    // customized block
+    bool cust = false, cust_digit = false, stanceL = true;
+    int swing_joint_id = 0;             // Pinocchio id
+    double sf_R[9], sf_p[3];            // swing-foot end transform
+    raptor_gait_desc gait;
 };
 
 static void legged_setup(raptor_problem& pr, const raptor_model* model, const LeggedSetup& S) {
@@ -723,12 +731,76 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     // layout, TalosSingleStepOptimizer.cpp:69-92 / DigitSingleStepOptimizer.cpp:74-94: [torque limits | joint limits | contact]
     const int rt = N * ni, rq = N * nv, rcn = N * 7;
     Q.off_tau = 0; Q.off_q = rt; Q.off_contact = rt + rq;
+    // customized block: rows in the reference's order, each a linear form of one sample's pose quantities
+    std::vector<DevCustRow> crow;
+    std::vector<double> clb, cub;
+    if (S.cust) {
+        if (S.swing_joint_id < 1 || S.swing_joint_id > nv) throw std::runtime_error("Can not find joint");
+        Q.sf_body = -1;
+        for (int g = 0; g < nb; g++)
+            if (Q.body_link[g] == S.swing_joint_id - 1) Q.sf_body = g;
+        if (Q.sf_body < 0) throw unsupported_error("legged kernel: the swing foot is not a body of the tree");
+        for (int k = 0; k < 9; k++) Q.sf_R[k] = S.sf_R[k];
+        for (int k = 0; k < 3; k++) Q.sf_p[k] = S.sf_p[k];
+        const raptor_gait_desc& gp = S.gait;
+        auto add = [&](int sample, int qa, double ca, int qb, double cb, int wrap, double addv, double lo, double hi) {
+            crow.push_back(DevCustRow{sample, qa, qb, wrap, ca, cb, addv});
+            clb.push_back(lo);
+            cub.push_back(hi);
+        };
+        const double e = gp.eps_torso_angle, yaw = S.stanceL ? M_PI_2 : -M_PI_2;
+        for (int i = 0; i < N; i++)  // g1: swing-foot height (compute_bounds :160-167)
+            add(i, 2, 1, -1, 0, 0, 0, (i == N / 2) ? gp.swingfoot_midstep_z_des : 0.0, (i == 0 || i == N - 1) ? 0.0 : 1e19);
+        for (int i = 0; i < N; i++) add(i, 3, 1, -1, 0, 1, 0, 0, 0);                                  // g2 roll
+        for (int i = 0; i < N; i++) add(i, 4, 1, -1, 0, 1, 0, 0, 0);                                  // g3 pitch
+        for (int i = 0; i < N; i++) add(i, 5, 1, -1, 0, 1, S.cust_digit ? yaw : 0.0, 0, 0);           // g4 yaw
+        if (S.cust_digit) {  // DigitCustomizedConstraints.cpp:103-124, 176-200
+            add(0, 0, 1, -1, 0, 0, 0, gp.swingfoot_begin_x_des, gp.swingfoot_begin_x_des);
+            add(0, 1, 1, -1, 0, 0, 0, gp.swingfoot_begin_y_des, gp.swingfoot_begin_y_des);
+            add(N - 1, 0, 1, -1, 0, 0, 0, gp.swingfoot_end_x_des, gp.swingfoot_end_x_des);
+            add(N - 1, 1, 1, -1, 0, 0, 0, gp.swingfoot_end_y_des, gp.swingfoot_end_y_des);
+            for (int i = 0; i < N; i++) add(i, 8, 1, -1, 0, 0, 0, 1.05, 1e19);                        // g6 torso height
+            for (int i = 0; i < N; i++) add(i, 6, 1, 0, -0.5, 0, 0, -0.05, 0.05);                     // g7
+            for (int i = 0; i < N; i++) add(i, 7, 1, 1, -0.5, 0, 0, -0.10, 0.10);                     // g8
+            for (int i = 0; i < N; i++) add(i, 9, 1, -1, 0, 1, 0, -e, e);                             // g9
+            for (int i = 0; i < N; i++) add(i, 10, 1, -1, 0, 1, 0, -e, e);                            // g10
+            for (int i = 0; i < N; i++) add(i, 11, 1, -1, 0, 1, yaw, -e, e);                          // g11
+        } else {  // TalosCustomizedConstraints.cpp:98-124, 176-200
+            add(0, 0, 1, -1, 0, 0, -gp.swingfoot_begin_x_des, 0, 0);
+            add(N - 1, 0, 1, -1, 0, 0, -gp.swingfoot_end_x_des, 0, 0);
+            for (int i = 0; i < N; i++) add(i, 1, 1, -1, 0, 0, -gp.swingfoot_begin_y_des, 0, 0);
+            for (int i = 0; i < N; i++) add(i, 8, 1, -1, 0, 0, 0, gp.torso_height_lb, 1e19);          // g6
+            for (int i = 0; i < N; i++) add(i, 9, 1, -1, 0, 1, 0, -e, e);                             // g7
+            for (int i = 0; i < N; i++) add(i, 10, 1, -1, 0, 1, 0, -e, e);                            // g8
+            for (int i = 0; i < N; i++) add(i, 11, 1, -1, 0, 1, 0, -e, e);                            // g9
+            for (int i = 0; i < N; i++) add(i, 7, 1, -1, 0, 0, 0, -1e19, 0);                          // g10
+            for (int i = 0; i < N; i++) add(i, 7, 1, 1, -1.0, 0, 0, 0, 1e19);                         // g11
+        }
+    }
+    Q.ncust = (int)crow.size();
+    Q.off_cust = rt + rq + rcn;
     std::memset(&p->hspheres, 0, sizeof(p->hspheres));
-    p->layout = DevLayout{rt + rq + rcn, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
-    p->num_blocks = 3;
+    p->layout = DevLayout{rt + rq + rcn + Q.ncust, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
+    p->num_blocks = S.cust ? 4 : 3;
     p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rcn;
+    p->block_offsets[4] = rt + rq + rcn + Q.ncust;
     p->g_lb.assign(p->layout.m, 0.0);
     p->g_ub.assign(p->layout.m, 0.0);
+    for (int r = 0; r < Q.ncust; r++) {
+        p->g_lb[Q.off_cust + r] = clb[r];
+        p->g_ub[Q.off_cust + r] = cub[r];
+    }
+    {   // per-sample row lists (always uploaded: the kernels take the pointers even when the block is absent)
+        std::vector<int> start(N + 1, 0), list(std::max(1, Q.ncust), 0);
+        for (const DevCustRow& c : crow) start[c.sample + 1]++;
+        for (int i = 0; i < N; i++) start[i + 1] += start[i];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int r = 0; r < Q.ncust; r++) list[fill[crow[r].sample]++] = r;
+        if (crow.empty()) crow.push_back(DevCustRow{0, 0, -1, 0, 0, 0, 0});
+        p->d_cust.upload(crow.data(), crow.size());
+        p->d_cust_list.upload(list.data(), list.size());
+        p->d_cust_start.upload(start.data(), start.size());
+    }
     for (int i = 0; i < N; i++) {
         for (int j = 0; j < ni; j++) {  // TorqueLimits.cpp:45-50
             p->g_lb[i * ni + j] = S.tl[j];
@@ -756,6 +828,8 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     Q.c_L = off; off += 6 * 3 * ni;
     Q.c_P = off; off += ni * 6;
     Q.c_Pl = off; off += (nd - 6) * 2;
+    Q.c_sf = off; off += 6;
+    Q.c_Psf = off; off += ni * 6;
     Q.c_stride = (off + 1) & ~1;
     for (int dd = 6; dd < nd; dd++) {
         Q.dep_col[dd][0] = Q.dep_col[dd][1] = -1;
@@ -792,6 +866,16 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
     S.tl = d->torque_limits_lower; S.tu = d->torque_limits_upper;
     S.jl = d->joint_limits_lower; S.ju = d->joint_limits_upper;
     S.mu = d->mu; S.gamma = d->gamma; S.Lx = d->Lx; S.Ly = d->Ly;
+    if (d->gait.enabled) {  // TalosSingleStepOptimizer.cpp:95-99
+        if (d->stance_leg != 'L' && d->stance_leg != 'R') throw std::runtime_error("Invalid stance leg input");
+        S.cust = true;
+        S.cust_digit = false;
+        S.stanceL = d->stance_leg == 'L';
+        S.swing_joint_id = d->gait.swing_joint_id;
+        for (int k = 0; k < 9; k++) S.sf_R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 3; k++) S.sf_p[k] = d->gait.swingfoot_endT_p[k];
+        S.gait = d->gait;
+    }
     legged_setup(*p, model, S);
     *out = p.release();
     API_CATCH
@@ -907,6 +991,14 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
                 }
             }
         }
+    }
+    if (d->gait.enabled) {  // DigitSingleStepOptimizer.cpp:97-101
+        S.cust = true;
+        S.cust_digit = true;
+        S.stanceL = sleg == 0;
+        S.swing_joint_id = d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1;
+        digit_stance_foot_endT(1 - sleg, S.sf_R, S.sf_p);  // DigitCustomizedConstraints.cpp:16-24
+        S.gait = d->gait;
     }
     std::unique_ptr<raptor_problem> p(new raptor_problem());
     legged_setup(*p, model, S);

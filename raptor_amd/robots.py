@@ -3,7 +3,7 @@ files and the model set-up of the example mains), as plain data for `ProblemHand
 from __future__ import annotations
 
 import dataclasses
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -31,6 +31,8 @@ class LeggedConfig:
     degree: int = 6
     T: float = 0.4
     N: int = 14
+    stance_leg: str = "L"
+    gait: Optional[dict] = None   # GaitParameters + swing foot (None: customized block left out)
 
 
 # ---- Talos: Examples/Talos/include/TalosConstants.h:7-96, TalosDynamicsConstraints.h:14-36 ----
@@ -65,7 +67,16 @@ def talos_config(m: RobotModel, stance_leg: str = "L") -> LeggedConfig:
         torque_limits_lower=-np.array(_TALOS_TL, dtype=float), torque_limits_upper=np.array(_TALOS_TL, dtype=float),
         joint_limits_lower=np.array(_TALOS_JL_LO, dtype=float), joint_limits_upper=np.array(_TALOS_JL_UP, dtype=float),
         mu=0.7, gamma=0.7, Lx=0.1344, Ly=0.2208,     # MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH
+        stance_leg="L" if stance_leg in "Ll" else "R",
     )
+
+
+def talos_gait(m: RobotModel, stance_leg: str = "L") -> dict:
+    """TalosCustomizedConstraints.h:12-19 GaitParameters defaults, .cpp:17-18 end transform, :191 torso height."""
+    swing = "leg_right_6_joint" if stance_leg in "Ll" else "leg_left_6_joint"
+    return dict(swing_joint_id=m.joint_id(swing) + 1, swingfoot_endT_p=(0.0, 0.0, -0.107), eps_torso_angle=np.deg2rad(1.5),
+                swingfoot_midstep_z_des=0.10, swingfoot_begin_x_des=0.0, swingfoot_begin_y_des=-0.17, swingfoot_end_x_des=0.0,
+                swingfoot_end_y_des=-0.17, torso_height_lb=0.95)
 
 
 # ---- Unitree-G1: Examples/Unitree-G1/include/G1Constants.h, G1DynamicsConstraints.h:14-36, G1SingleStep.cpp:18-43 ----
@@ -115,7 +126,16 @@ def g1_config(m: RobotModel, stance_leg: str = "L") -> LeggedConfig:
         torque_limits_lower=-np.array(tl, dtype=float), torque_limits_upper=np.array(tl, dtype=float),
         joint_limits_lower=np.array(lo, dtype=float), joint_limits_upper=np.array(up, dtype=float),
         mu=0.7, gamma=0.7, Lx=0.10, Ly=0.03,
+        stance_leg="L" if stance_leg in "Ll" else "R",
     )
+
+
+def g1_gait(m: RobotModel, stance_leg: str = "L") -> dict:
+    """G1CustomizedConstraints.h:12-19, .cpp:17-18, :185."""
+    swing = "right_ankle_roll_joint" if stance_leg in "Ll" else "left_ankle_roll_joint"
+    return dict(swing_joint_id=m.joint_id(swing) + 1, swingfoot_endT_p=(0.035, 0.0, -0.03), eps_torso_angle=np.deg2rad(1.0),
+                swingfoot_midstep_z_des=0.10, swingfoot_begin_x_des=0.0, swingfoot_begin_y_des=-0.237013, swingfoot_end_x_des=0.0,
+                swingfoot_end_y_des=-0.237013, torso_height_lb=0.55)
 
 
 # ---- Digit-v3: Examples/Digit/include/DigitConstants.h, DigitDynamicsConstraints.h:19-57, DigitSingleStep.cpp:16-40 ----
@@ -151,6 +171,7 @@ class DigitConfig:
     degree: int = 5
     T: float = 0.4
     N: int = 14
+    gait: Optional[dict] = None   # GaitParameters (None: customized block left out)
 
     @property
     def independent_ids(self):
@@ -188,3 +209,9 @@ def digit_config(m: RobotModel, stance_leg: str = "L") -> DigitConfig:
         joint_limits_lower=np.deg2rad(np.array(_DIGIT_JL_LO, dtype=float)),
         joint_limits_upper=np.deg2rad(np.array(_DIGIT_JL_UP, dtype=float)),
     )
+
+
+def digit_gait() -> dict:
+    """singlestep_optimization_settings.yaml:13-22 over the GaitParameters defaults (DigitCustomizedConstraints.h:12-19)."""
+    return dict(eps_torso_angle=0.02, swingfoot_midstep_z_des=0.10, swingfoot_begin_x_des=-0.22, swingfoot_begin_y_des=0.0,
+                swingfoot_end_x_des=-0.22, swingfoot_end_y_des=0.0)

@@ -47,7 +47,7 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
-def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None):
+def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, customized=False):
     """Talos / Unitree-G1 single-step problem (TalosSingleStepOptimizer.cpp:17-124, G1 twin)."""
     import os
 
@@ -64,13 +64,15 @@ def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None):
         cfg.stance_foot_T_des_R, cfg.stance_foot_T_des_p = T_des
     if degree is not None:
         cfg.degree = degree
+    if customized:
+        cfg.gait = (robots.talos_gait if which == "talos" else robots.g1_gait)(m, stance)
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV)
     return A.ProblemHandle.legged(api, mh, t, cfg), m, cfg
 
 
-def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None):
+def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customized=False):
     """Digit-v3 single-step problem (DigitSingleStepOptimizer.cpp:17-124)."""
     import os
 
@@ -83,6 +85,8 @@ def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None):
         cfg.stance_foot_T_des_R, cfg.stance_foot_T_des_p = T_des
     if degree is not None:
         cfg.degree = degree
+    if customized:
+        cfg.gait = robots.digit_gait()
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV)

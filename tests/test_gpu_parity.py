@@ -446,3 +446,31 @@ def test_costs(oracle, hip, robot):
     Fh2, none = ph.costs_host(Z, kinds, derivatives=False)
     assert none is None
     check(Fh2, Fo)
+
+
+@pytest.mark.parametrize("robot,stance", [("digit", "L"), ("digit", "R"), ("talos", "L"), ("g1", "R")])
+def test_customized_block(oracle, hip, robot, stance):
+    """Fourth block: DigitCustomizedConstraints (N*10 + 4 rows) / Talos / G1 CustomizedConstraints (N*11 + 2 rows):
+    swing-foot and torso rows, ordered by quantity then sample, with their bounds."""
+    N = 7
+    keep = []
+    if robot == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance, customized=True)
+        ph, _, _ = H.digit_problem(hip, keep, N=N, stance=stance, customized=True)
+        rows = N * 10 + 4
+    else:
+        po, m, cfg = H.legged_problem(oracle, robot, keep, N=N, stance=stance, customized=True)
+        ph, _, _ = H.legged_problem(hip, robot, keep, N=N, stance=stance, customized=True)
+        rows = N * 11 + 2
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    assert po.block_offsets[4] - po.block_offsets[3] == rows
+    lo, uo = po.bounds()
+    lh, uh = ph.bounds()
+    assert np.array_equal(lo, lh) and np.array_equal(uo, uh)
+    Z = 0.1 * np.random.default_rng(20250523 + 8).uniform(-1, 1, (4, po.n))
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    Gh2, _ = ph.eval_host(Z, A.EVAL_G)
+    check(Gh2, Gh, 1e-12)

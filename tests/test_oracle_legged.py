@@ -134,3 +134,30 @@ def test_costs_gradient_finite_differences(oracle, robot):
     # ||q_d(0)|| of an all-zero trajectory: below the square-root threshold the gradient stays zero (:26)
     F0, G0 = p.costs_host(np.zeros((1, p.n)), kinds[2:])
     assert np.all(F0 == 0) and np.all(G0 == 0)
+
+
+@pytest.mark.parametrize("robot", ["digit", "talos"])
+def test_customized_block_layout_and_fd(oracle, robot):
+    from raptor_amd import _capi as A
+
+    keep = []
+    N = 5
+    if robot == "digit":
+        p, m, cfg = H.digit_problem(oracle, keep, N=N, customized=True)
+        rows, ndyn = N * 10 + 4, 72
+    else:
+        p, m, cfg = H.legged_problem(oracle, robot, keep, N=N, customized=True)
+        rows, ndyn = N * 11 + 2, 84
+    off = p.block_offsets[3]
+    assert p.block_offsets[4] - off == rows == p.m - off
+    lb, ub = p.bounds()
+    assert lb[off + N // 2] == cfg.gait["swingfoot_midstep_z_des"] and ub[off] == 0 and ub[off + N - 1] == 0 and ub[off + 1] == 1e19
+    Z = 0.1 * np.random.default_rng(6).uniform(-1, 1, (1, p.n))
+    G, J = p.eval_host(Z)
+    h = 1e-6
+    for c in range(0, ndyn, 6):
+        zp, zm = Z.copy(), Z.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        fd = (p.eval_host(zp, A.EVAL_G)[0][0, off:] - p.eval_host(zm, A.EVAL_G)[0][0, off:]) / (2 * h)
+        assert np.abs(fd - J[0, off:, c]).max() < 1e-6
