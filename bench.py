@@ -60,8 +60,7 @@ class Legged:
     """BASELINE configs[2] (Talos) / configs[4] (G1, one GPU's shard of the 8192-problem sweep)."""
     samples = 14
     batch = 1024
-    rows = 12 + 18 + 7
-    bytes_per_se = rows * 8 * (108 + 1)   # SURVEY.md 8d: 8 R (V + 1)
+    bytes_per_se = None                   # 8 (m / N) (n + 1): every row written once, g and pg_pz (SURVEY.md 8d)
     flops_per_se = 230000                 # SURVEY.md 8d total for Talos / G1 as the reference does it
     dominant = 1
     kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows)",
@@ -73,12 +72,12 @@ class Legged:
         self.name = which
         self.workload = (f"{'Talos' if which == 'talos' else 'Unitree-G1'} single-step gait, nv=18 (6 floating + 12), Bezier degree 6, "
                          f"14 Chebyshev samples x {self.batch} random z in 0.1*U(-1,1)^108 per GPU, eval_g+eval_jac_g "
-                         "(torque limits + constrained joint limits + rectangle contact), no solver")
+                         "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows), no solver")
 
     def build(self, api, keep):
         import helpers as H
 
-        return H.legged_problem(api, self.name, keep, N=self.samples)[0]
+        return H.legged_problem(api, self.name, keep, N=self.samples, customized=True)[0]
 
 
 class Digit:
@@ -86,8 +85,7 @@ class Digit:
     name = "digit"
     samples = 14
     batch = 4096
-    rows = 12 + 36 + 7
-    bytes_per_se = rows * 8 * (132 + 1)   # 8 R (V + 1) for the rows built (torque, joint limits, contact)
+    bytes_per_se = None                   # 8 (m / N) (n + 1) for the rows built (torque, joint limits, contact, customized)
     flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
     dominant = 1
     kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows)",
@@ -96,12 +94,13 @@ class Digit:
     z_scale = 0.1  # DigitSingleStep.cpp:75
     workload = ("Digit-v3 single-step gait, nv=36 (6 floating + 12 actuated + 18 closed-loop), Bezier degree 5, "
                 "14 Chebyshev samples x 4096 random z in 0.1*U(-1,1)^132 per GPU, eval_g+eval_jac_g "
-                "(torque limits + constrained joint limits + rectangle contact), no solver")
+                "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows: "
+                "914 of the reference's 1005 rows, the periodicity block is not built), no solver")
 
     def build(self, api, keep):
         import helpers as H
 
-        return H.digit_problem(api, keep, N=self.samples)[0]
+        return H.digit_problem(api, keep, N=self.samples, customized=True)[0]
 
 
 WORKLOADS = {"kinova": Kinova, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1"), "digit": Digit}
@@ -182,7 +181,8 @@ def main() -> None:
         dom_ms = kms[W.dominant]
         dom_s = dom_ms * 1e-3
         tot_s = (k0_ms + k1_ms) * 1e-3
-        alg_bytes = sample_evals * W.bytes_per_se
+        bytes_per_se = W.bytes_per_se or 8.0 * prob.m / W.samples * (prob.n + 1)
+        alg_bytes = sample_evals * bytes_per_se
         ms_per_step = 1e3 * elapsed / args.steps
         out = {
             "metric": "RNEA+dtau/dz sample-evals/sec (fp64)",
@@ -214,6 +214,7 @@ def main() -> None:
                 "kernel_ms": dom_ms,
                 "launches_timed": n_prof,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_per_sample_eval": bytes_per_se,
             },
             "roofline_fp64": {
                 "kernel": "all kernels of one evaluation",

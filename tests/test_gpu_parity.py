@@ -474,3 +474,37 @@ def test_customized_block(oracle, hip, robot, stance):
     check(Jh, Jo)
     Gh2, _ = ph.eval_host(Z, A.EVAL_G)
     check(Gh2, Gh, 1e-12)
+
+
+def test_legged_ragged_and_degenerate_sizes(oracle, hip):
+    """Odd batch x odd sample counts (half-filled wavefronts), N = 1, an empty batch, and error codes."""
+    keep = []
+    po, m, cfg = H.digit_problem(oracle, keep, N=5, customized=True)
+    ph, _, _ = H.digit_problem(hip, keep, N=5, customized=True)
+    Z = 0.1 * np.random.default_rng(12).uniform(-1, 1, (3, po.n))  # 15 sample-evals: last wavefront half empty
+    for a, b in zip(ph.eval_host(Z), po.eval_host(Z)):
+        check(a, b)
+    Gh, Jh = ph.eval_host(np.zeros((0, ph.n)))
+    assert Gh.shape == (0, ph.m) and Jh.shape == (0, ph.m, ph.n)
+    assert hip.fn("eval_batch_host")(ph.handle, None, 1, A.EVAL_G, None, None) == A.ERR_INVALID_ARGUMENT
+    # N = 1 (Uniform time: tspan = {T})
+    from raptor_amd import robots
+    import os
+    rd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
+    mt = robots.talos_model(os.path.join(rd, "talos_reduced_armfixed_floatingbase.urdf"))
+    ct = robots.talos_config(mt)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, ct.T, 1, 12, ct.degree, A.TIME_UNIFORM)
+    mo, mh = oracle.model_create(mt), hip.model_create(mt)
+    keep += [mo, mh]
+    p1o, p1h = A.ProblemHandle.legged(oracle, mo, t, ct), A.ProblemHandle.legged(hip, mh, t, ct)
+    Z1 = 0.1 * np.random.default_rng(13).uniform(-1, 1, (5, p1o.n))
+    for a, b in zip(p1h.eval_host(Z1), p1o.eval_host(Z1)):
+        check(a, b)
+    # wiring errors are reported the same way on both sides
+    bad = robots.talos_config(mt)
+    bad.independent_ids = bad.independent_ids[:-1] + [bad.independent_ids[0]]  # duplicate id
+    for api, mm in ((oracle, mo), (hip, mh)):
+        with pytest.raises(A.RaptorInvalidArgument):
+            A.ProblemHandle.legged(api, mm, A.make_traj_desc(keep, A.TRAJ_BEZIER, ct.T, 4, 12, ct.degree, A.TIME_CHEBYSHEV), bad)
+        with pytest.raises(A.RaptorInvalidArgument):  # single-step optimizers use BezierCurves
+            A.ProblemHandle.legged(api, mm, A.make_traj_desc(keep, A.TRAJ_POLYNOMIAL, ct.T, 4, 12, 3, A.TIME_CHEBYSHEV), ct)
