@@ -357,6 +357,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // lane evaluates this sample's rows from its own pose and the floating-base coordinates of the torso's lane
     const bool is_sf = Q->ncust > 0 && has_body && g == Q->sf_body;
     M3 Rsf;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rsf.m[k] = 0.0;
     V3 psf = v3(0, 0, 0);
     if (Q->ncust > 0) {
         double X[12];
@@ -431,54 +433,45 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     wave_sync();
 
-    // ---- phase F: for every independent joint `it`: d(tree torques, root wrench, torso twist)/d(q, v, a)_it ----
+    // ---- phase F1: column pass.  Lane t < ni = actuator column t: d(root wrench), torso twist, swing-foot twist per unit
+    // (q, v, a) of actuator t, summed over the tree joints that move with it (<= 8).  These are whole-tree quantities with
+    // no row structure, so one lane per column is the natural mapping.
+    {
+        const int tb = Q->torso_body, sb = (Q->ncust > 0) ? Q->sf_body : 0;
+        M3 Rt, Rs;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            Rt.m[k] = __shfl(Rw.m[k], tb, LG);
+            Rs.m[k] = __shfl(Rsf.m[k], sb, LG);
+        }
+        const V3 ot = v3(__shfl(ow.x, tb, LG), __shfl(ow.y, tb, LG), __shfl(ow.z, tb, LG));
+        const V3 ps = v3(__shfl(psf.x, sb, LG), __shfl(psf.y, sb, LG), __shfl(psf.z, sb, LG));
+        const bool col = g < ni;
+        const int t = col ? g : 0;
+        const int ns = col ? Q->col_nsupp[t] : 0;
+        SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), twt = sv_zero(), tws = sv_zero();
 #pragma unroll 1
-    for (int it = 0; it < ni; it++) {
-        const int ns = Q->col_nsupp[it];
-        double Tq = 0.0, Tv = 0.0, Ta = 0.0;
-        SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), tw = sv_zero();
-        for (int r = 0; r < ns; r++) {
-            const int k = Q->col_supp_body[it][r];
-            const int kend = Q->body_end[k];
-            const double* vk = sl + LL::V + k * LEG_VEC;
-            const bool s1 = Q->col_supp_slot[it][r] != 0;  // uniform
-            const double g0 = __shfl(s1 ? w1[0] : w0[0], k, LG), hv = __shfl(s1 ? w1[1] : w0[1], k, LG),
-                         hq = __shfl(s1 ? w1[2] : w0[2], k, LG);
-            if (has_joint) {
-                double dq = 0.0, dv = 0.0, da = 0.0;
-                if (k > g && k < gend) {  // this joint is a strict ancestor of k
-                    da = dot(s, lds_sv(vk + 18));
-                    dv = dot(s, lds_sv(vk + 24));
-                    dq = dot(s, lds_sv(vk + 30));
-                } else if (g >= k && g < kend) {  // k is this joint or one of its ancestors
-                    const SV sk = lds_sv(vk), sdk = lds_sv(vk + 6), psik = lds_sv(vk + 12);
-                    da = dot(IS, sk);
-                    dv = 2.0 * dot(IS, sdk) + dot(BtS, sk);
-                    dq = dot(IS, psik) + dot(BtS, sdk);
-                    if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
-                        da += M->armature[jnt];
-                        dv += M->damping[jnt];
-                    }
-                }
-                Ta += da * g0;
-                Tv += dv * g0 + da * hv;
-                Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
-            }
-            if (g == 0) {  // root wrench
-                const SV ISk = lds_sv(vk + 18), cvk = lds_sv(vk + 24), cqk = lds_sv(vk + 30);
+        for (int r = 0; r < 8; r++) {
+            const bool on = r < ns;
+            const int k = on ? Q->col_supp_body[t][r] : 1;
+            const bool s1 = on && Q->col_supp_slot[t][r] != 0;
+            const double a0 = __shfl(w0[0], k, LG), a1 = __shfl(w0[1], k, LG), a2 = __shfl(w0[2], k, LG);
+            const double b0 = __shfl(w1[0], k, LG), b1 = __shfl(w1[1], k, LG), b2 = __shfl(w1[2], k, LG);
+            if (on) {
+                const double g0 = s1 ? b0 : a0, hv = s1 ? b1 : a1, hq = s1 ? b2 : a2;
+                const double* vk = sl + LL::V + k * LEG_VEC;
+                const SV sk = lds_sv(vk), ISk = lds_sv(vk + 18), cvk = lds_sv(vk + 24), cqk = lds_sv(vk + 30);
                 Fa = Fa + ISk * g0;
                 Fv = Fv + cvk * g0 + ISk * hv;
                 Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
+                const int kend = Q->body_end[k];
+                if (tb >= k && tb < kend) twt = twt + sk * g0;
+                if (Q->ncust > 0 && sb >= k && sb < kend) tws = tws + sk * g0;
             }
-            if ((is_torso || is_sf) && g >= k && g < kend) tw = tw + lds_sv(vk) * g0;  // body twist per unit rate of `it`
         }
-        if (has_joint) {
-            double* ts = sl + LL::TS + g * 3;
-            ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
-        }
-        if (g == 0) {  // d(lambda.tail(6))
+        if (col) {
 #pragma unroll
-            for (int x = 0; x < 3; x++) {
+            for (int x = 0; x < 3; x++) {  // d(lambda.tail(6)) = root wrench about the contact point, RPY rows through A_des
                 const SV w = (x == 0) ? Fq : ((x == 1) ? Fv : Fa);
                 const V3 np = w.a - cross(pf, w.l);
                 const double lm[6] = {w.l.x, w.l.y, w.l.z,
@@ -486,22 +479,64 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                                       Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
                                       Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
 #pragma unroll
-                for (int r = 0; r < 6; r++) rec[Q->c_L + (it * 3 + x) * 6 + r] = lm[r];
+                for (int r = 0; r < 6; r++) rec[Q->c_L + (t * 3 + x) * 6 + r] = lm[r];
+            }
+            {   // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
+                const V3 lin = twt.l + cross(twt.a, ot);
+                const V3 rot = rpy_rates(Rt, twt.a);
+                const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
+#pragma unroll
+                for (int k = 0; k < 6; k++) rec[Q->c_P + t * 6 + k] = pc[k];
+            }
+            if (Q->ncust > 0) {  // swing-foot pose derivative (FK Jacobians times pq_pz, DigitCustomizedConstraints.cpp:80-82)
+                const V3 lin = tws.l + cross(tws.a, ps);
+                const V3 rot = rpy_rates(Rs, tws.a);
+                const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
+#pragma unroll
+                for (int k = 0; k < 6; k++) rec[Q->c_Psf + t * 6 + k] = pc[k];
             }
         }
-        if (is_torso) {  // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
-            const V3 lin = tw.l + cross(tw.a, ow);
-            const V3 rot = rpy_rates(Rw, tw.a);
-            const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
-#pragma unroll
-            for (int k = 0; k < 6; k++) rec[Q->c_P + it * 6 + k] = pc[k];
+    }
+
+    // ---- phase F2: row pass.  Lane = tree joint j (row), loop over actuator columns `it` and the joints k that move with
+    // it.  One code path for both relations: with (A, U1, U2, U3) = (s_j; IS_k, cv_k, cq_k) when j is a strict ancestor of
+    // k and (IS_j; s_k, sd_k, psi_k) when k is j or an ancestor of j,
+    //     M_jk = A.U1,   dtau_j/dv_k = f A.U2 + BtS_j.U1,   dtau_j/dq_k = A.U3 + BtS_j.U2     (f = 1 / 2, BtS terms only in
+    // the second case); both vector triples sit 18 doubles apart in the LDS slots, so the choice is an address offset.
+    const double* vme = sl + LL::V + g * LEG_VEC;
+#pragma unroll 1
+    for (int it = 0; it < ni; it++) {
+        const int ns = Q->col_nsupp[it];
+        double Tq = 0.0, Tv = 0.0, Ta = 0.0;
+        for (int r = 0; r < ns; r++) {
+            const int k = Q->col_supp_body[it][r];
+            const int kend = Q->body_end[k];
+            const bool s1 = Q->col_supp_slot[it][r] != 0;  // uniform
+            const double g0 = __shfl(s1 ? w1[0] : w0[0], k, LG), hv = __shfl(s1 ? w1[1] : w0[1], k, LG),
+                         hq = __shfl(s1 ? w1[2] : w0[2], k, LG);
+            const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
+            const bool dsc = has_joint && g >= k && g < kend;    // k is this joint or one of its ancestors
+            const double* vk = sl + LL::V + k * LEG_VEC + (anc ? 18 : 0);
+            const SV A = lds_sv(vme + (anc ? 0 : 18));
+            const SV U1 = lds_sv(vk), U2 = lds_sv(vk + 6), U3 = lds_sv(vk + 12);
+            double da = dot(A, U1);
+            const double t2 = dot(A, U2), t3 = dot(A, U3);
+            const double e2 = dot(BtS, U1), e3 = dot(BtS, U2);
+            double dv = anc ? t2 : 2.0 * t2 + e2;
+            double dq = anc ? t3 : t3 + e3;
+            if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
+                da += M->armature[jnt];
+                dv += M->damping[jnt];
+            }
+            const double rel = (anc || dsc) ? 1.0 : 0.0;
+            da *= rel; dv *= rel; dq *= rel;
+            Ta += da * g0;
+            Tv += dv * g0 + da * hv;
+            Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
         }
-        if (is_sf) {  // swing-foot pose derivative (translation / RPY Jacobian times pq_pz, DigitCustomizedConstraints.cpp:80-82)
-            const V3 lin = tw.l + cross(tw.a, psf);
-            const V3 rot = rpy_rates(Rsf, tw.a);
-            const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
-#pragma unroll
-            for (int k = 0; k < 6; k++) rec[Q->c_Psf + it * 6 + k] = pc[k];
+        if (has_joint) {
+            double* ts = sl + LL::TS + g * 3;
+            ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
         }
         wave_sync();
         if (tj >= 0) {  // project the rows: G^T
