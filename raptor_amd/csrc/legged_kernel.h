@@ -503,7 +503,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // k and (IS_j; s_k, sd_k, psi_k) when k is j or an ancestor of j,
     //     M_jk = A.U1,   dtau_j/dv_k = f A.U2 + BtS_j.U1,   dtau_j/dq_k = A.U3 + BtS_j.U2     (f = 1 / 2, BtS terms only in
     // the second case); both vector triples sit 18 doubles apart in the LDS slots, so the choice is an address offset.
-    const double* vme = sl + LL::V + g * LEG_VEC;
 #pragma unroll 1
     for (int it = 0; it < ni; it++) {
         const int ns = Q->col_nsupp[it];
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
             const bool dsc = has_joint && g >= k && g < kend;    // k is this joint or one of its ancestors
             const double* vk = sl + LL::V + k * LEG_VEC + (anc ? 18 : 0);
-            const SV A = lds_sv(vme + (anc ? 0 : 18));
+            const SV A = anc ? s : IS;  // registers: per-lane LDS slots 288 B apart would bank-conflict on 128-bit reads
             const SV U1 = lds_sv(vk), U2 = lds_sv(vk + 6), U3 = lds_sv(vk + 12);
             double da = dot(A, U1);
             const double t2 = dot(A, U2), t3 = dot(A, U3);
