@@ -282,6 +282,11 @@ int raptor_eval_costs(raptor_problem* problem, const double* d_Z, int B, int num
 int raptor_eval_costs_host(raptor_problem* problem, const double* Z, int B, int num_costs, const int* kinds, double* F,
                            double* GRAD);
 
+/* Measurement aid with no counterpart in the reference: `blocks` workgroups each fill one contiguous chunk of
+ * `chunk_doubles` doubles with 16-byte stores -- the write pattern of the Jacobian kernels, used by scripts/bw_probe.py
+ * to calibrate the achievable HBM write rate next to the roofline numbers. */
+int raptor_probe_fill(double* d_p, long long blocks, long long chunk_doubles, void* stream);
+
 /* Device selection for the calling process (one process per GPU): hipSetDevice + probe. */
 int raptor_init(int device);
 

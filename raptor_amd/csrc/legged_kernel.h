@@ -30,6 +30,9 @@
 #include "kinova_kernel.h"
 
 #define LEG_BLOCK 64      // core kernel: one wavefront per workgroup (no workgroup barrier anywhere)
+#ifndef LEG_EXP_BLOCK
+#define LEG_EXP_BLOCK 256  // streaming kernel: threads per workgroup (one workgroup per sample-eval)
+#endif
 #define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
@@ -561,6 +564,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 // (rows i*R .. i*R + R - 1 of a block), written with one 16-byte store per lane and no integer division in the loop.
 //   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
 //   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
+// 16-byte store of two adjacent columns
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+RD void store2_stream(double* p, double a, double b) {
+    v2d_t v = {a, b};
+#ifdef RAPTOR_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+#else
+    *reinterpret_cast<v2d_t*>(p) = v;  // plain stores measured faster than nontemporal ones at the 4 GB bench size
+#endif
+}
+
 template <int PIECE>
 RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, double* __restrict__ dst,
                             const double* __restrict__ rec, const double* __restrict__ wB, const int* __restrict__ tcol,
@@ -571,11 +585,11 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
     const double* Pl = rec + Q->c_Pl;
     const double* lam = rec + Q->c_lam;
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
-    const int dr = (2 * RAPTOR_BLOCK) / n, dc = (2 * RAPTOR_BLOCK) - dr * n;
+    const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
     const int total = R * n;
     int el = 2 * tid;
     int r = el / n, c = el - r * n;
-    for (; el < total; el += 2 * RAPTOR_BLOCK) {
+    for (; el < total; el += 2 * LEG_EXP_BLOCK) {
         double o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -609,7 +623,7 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
             }
             o[h] = val;
         }
-        *reinterpret_cast<double2*>(dst + el) = make_double2(o[0], o[1]);
+        store2_stream(dst + el, o[0], o[1]);
         r += dr;
         c += dc;
         if (c >= n) { c -= n; r++; }
@@ -622,11 +636,11 @@ RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int
                            const double* __restrict__ wB, const int* __restrict__ tcol, const DevLegged* __restrict__ Q) {
     const double* Pb = rec + Q->c_P;
     const double* Ps = rec + Q->c_Psf;
-    const int dr = (2 * RAPTOR_BLOCK) / n, dc = (2 * RAPTOR_BLOCK) - dr * n;
+    const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
     const int total = nrows * n;
     int el = 2 * tid;
     int r = el / n, c = el - r * n;
-    for (; el < total; el += 2 * RAPTOR_BLOCK) {
+    for (; el < total; el += 2 * LEG_EXP_BLOCK) {
         const int row = list[r];
         const DevCustRow cr = cust[row];
         double o[2];
@@ -642,14 +656,14 @@ RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int
             }
             o[h] = val;
         }
-        *reinterpret_cast<double2*>(blockbase + (size_t)row * n + c) = make_double2(o[0], o[1]);
+        store2_stream(blockbase + (size_t)row * n + c, o[0], o[1]);
         r += dr;
         c += dc;
         if (c >= n) { c -= n; r++; }
     }
 }
 
-__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTraj* __restrict__ T,
+__global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevTraj* __restrict__ T,
                                                                      const DevLegged* __restrict__ Q,
                                                                      const double* __restrict__ basis, const DevLayout L,
                                                                      const double* __restrict__ core,
@@ -671,8 +685,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_kernel(const DevTr
     int* tcol = reinterpret_cast<int*>(wB + 3 * ndyn);           // [ndyn]
     int* rowinfo = tcol + ndyn;                                  // [MAX_NV] row kind, then [MAX_NV][2] dep_col
     const double* src = core + (size_t)e * stride;
-    for (int k = tid; k < stride; k += RAPTOR_BLOCK) rec[k] = src[k];
-    for (int c = tid; c < ndyn; c += RAPTOR_BLOCK) {
+    for (int k = tid; k < stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
+    for (int c = tid; c < ndyn; c += LEG_EXP_BLOCK) {
         const int t = c / K, k = c - t * K;
         const double* Bs = basis + (size_t)(i * 3) * K + k;
         wB[c] = Bs[0];

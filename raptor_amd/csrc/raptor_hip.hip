@@ -352,7 +352,7 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
         const int ndyn = p.hleg.ni * p.hleg.K;
         const size_t lds_bytes = (size_t)(p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
-        hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)E), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_leg.p,
+        hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)E), dim3(LEG_EXP_BLOCK), lds_bytes, st, p.d_traj.p, p.d_leg.p,
                            p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, dJ);
     } else {
         const long long total = (long long)B * p.layout.m * p.layout.n;
@@ -392,7 +392,18 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
 
 }  // namespace
 
+// bandwidth probe (scripts/bw_probe.py): every workgroup writes one contiguous chunk with 16-byte stores per lane
+__global__ __launch_bounds__(256) void probe_fill_kernel(double* __restrict__ p, const long long chunk) {
+    double* dst = p + (long long)blockIdx.x * chunk;
+    for (long long el = 2 * threadIdx.x; el < chunk; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
+}
+
 extern "C" {
+
+int raptor_probe_fill(double* d_p, long long blocks, long long chunk_doubles, void* stream) {
+    hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, chunk_doubles);
+    return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
+}
 
 const char* raptor_last_error(void) { return g_err.c_str(); }
 

@@ -14,3 +14,13 @@ ms = t(lambda: x.fill_(1.0)); print(f"fill  {n*8/1e9:.2f} GB  {ms:.3f} ms  {n*8/
 ms = t(lambda: x.zero_()); print(f"zero  {n*8/1e9:.2f} GB  {ms:.3f} ms  {n*8/ms/1e6:.0f} GB/s written")
 ms = t(lambda: y.copy_(x[: n // 2])); print(f"copy  {n*4/1e9:.2f} GB  {ms:.3f} ms  {n*4/ms/1e6:.0f} GB/s written (+ same read)")
 ms = t(lambda: x.sum()); print(f"sum   {n*8/1e9:.2f} GB  {ms:.3f} ms  {n*8/ms/1e6:.0f} GB/s read")
+
+# the library's own block-contiguous pattern (one workgroup per contiguous chunk, 16 B per lane)
+import ctypes, os
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raptor_amd", "libraptor_hip.so"))
+lib.raptor_probe_fill.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p]
+st = torch.cuda.current_stream().cuda_stream
+for chunk in (8624, 8628, 8624 * 14, 1584, 4752, 924, 132):
+    blocks = n // chunk
+    ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), blocks, chunk, st))
+    print(f"probe chunk {chunk*8/1024:.0f} KB x {blocks} blocks: {ms:.3f} ms  {blocks*chunk*8/ms/1e6:.0f} GB/s")
