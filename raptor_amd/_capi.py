@@ -192,6 +192,8 @@ EXPORTS = [
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
 ]
+# entry points that exist on the device library only (no oracle counterpart: nothing to compare)
+DEVICE_ONLY_EXPORTS = ["probe_fill"]
 
 
 class CApi:
@@ -228,6 +230,8 @@ class CApi:
         f("eval_costs_host").argtypes = [vp, _dp, C.c_int, C.c_int, _ip, _dp, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
+        if prefix == "raptor_":
+            f("probe_fill").argtypes = [vp, C.c_longlong, C.c_longlong, vp]
         self._f = f
 
     # -- helpers -------------------------------------------------------------------------

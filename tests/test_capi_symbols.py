@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(raptor_amd.LIB_PATH)
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert sorted("raptor_" + e for e in _capi.EXPORTS) == syms
+    assert sorted("raptor_" + e for e in _capi.EXPORTS + _capi.DEVICE_ONLY_EXPORTS) == syms
 
 
 def test_oracle_exports_same_surface(oracle):
