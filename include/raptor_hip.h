@@ -113,12 +113,30 @@ typedef struct raptor_gait_desc {
 } raptor_gait_desc;
 
 /*
+ * The reset-map ("periodicity") block that closes a single walking step:
+ *   DigitSingleStepPeriodicityConstraints  Examples/Digit/src/DigitSingleStepPeriodicityConstraints.cpp:6-226
+ *   TalosSingleStepPeriodicityConstraints  Examples/Talos/src/TalosSingleStepPeriodicityConstraints.cpp:6-226 (G1 twin)
+ * rows: [H (v+ - v-) - J^T lambda (nv) | J v+ (n_dep) | position reset (Nact) | velocity reset (Nact) | contact on lambda (7)]
+ * with q-, v- the last sample, J the constraint Jacobian after the stance swap, v+ = z.segment(varLength - nv - n_dep, nv)
+ * and lambda = z.tail(n_dep): `extra_variables` must be nv + n_dep.  `enabled == 0` leaves the block out.
+ */
+typedef struct raptor_period_desc {
+    int enabled;
+    int swing_contact_joint_id;     /* contact_joint_id after dcPtr_->reinitialize() (Pinocchio id); Digit: derived    */
+    double swing_foot_endT_p[3];    /* stance_foot_endT.p after the swap; Digit: compiled in                           */
+    const int* joint_id1;           /* [num_independent] getJointId(JOINT_MAP[i][0]) - 1; Digit: derived               */
+    const int* joint_id2;           /* [num_independent] getJointId(JOINT_MAP[i][1]) - 1                               */
+    double mirror_sign;             /* g3 = q_0(id1) + mirror_sign * q_minus(id2): -1 Talos / G1; Digit: +1, derived   */
+} raptor_period_desc;
+
+/*
  * Floating-base robot whose six base joints are made dependent by a planted stance foot: the arguments of
  * TalosSingleStepOptimizer::set_parameters / G1SingleStepOptimizer::set_parameters that reach the hot path
  * (Examples/Talos/src/TalosSingleStepOptimizer.cpp:17-124, TalosDynamicsConstraints.cpp:6-42, same for Unitree-G1).
- * Blocks built: [torque limits N*Nact | joint limits N*nv | contact N*7 | customized N*11 + 2 (optional)]
- * (TorqueLimits, ConstrainedJointLimits, RectangleSurfaceContactConstraints, *CustomizedConstraints; the periodicity
- * block is not built yet).
+ * Blocks built: [torque limits N*Nact | joint limits N*nv | contact N*7 | customized N*11 + 2 (optional) |
+ * reset map nv + 6 + 2 Nact + 7 (optional)]
+ * (TorqueLimits, ConstrainedJointLimits, RectangleSurfaceContactConstraints, *CustomizedConstraints,
+ * *SingleStepPeriodicityConstraints).
  */
 typedef struct raptor_legged_desc {
     raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = num_independent                                 */
@@ -139,6 +157,7 @@ typedef struct raptor_legged_desc {
     double mu, gamma, Lx, Ly;       /* rectangleContactSurfaceParams(MU, GAMMA, FOOT_WIDTH, FOOT_LENGTH)           */
     int stance_leg;                 /* 'L' or 'R' (only the customized block reads it)                             */
     raptor_gait_desc gait;          /* fourth block: TalosCustomizedConstraints / G1CustomizedConstraints          */
+    raptor_period_desc period;      /* fifth block: TalosSingleStepPeriodicityConstraints / G1 twin                */
 } raptor_legged_desc;
 
 /*
@@ -147,7 +166,8 @@ typedef struct raptor_legged_desc {
  * (Examples/Digit/include/DigitDynamicsConstraints.h:19-57).  The closed-loop constants (rod / anchor end points,
  * stance-foot end transform, initial-guess fit) are compiled in, as the reference hard-codes them
  * (DigitDynamicsConstraints.h:178-198, DigitDynamicsConstraints.cpp:255-314).
- * Blocks built: [torque limits N*12 | joint limits N*36 | contact N*7 | customized N*10 + 4 (optional)].
+ * Blocks built: [torque limits N*12 | joint limits N*36 | contact N*7 | customized N*10 + 4 (optional) |
+ * reset map 91 (optional)].
  */
 typedef struct raptor_digit_desc {
     raptor_traj_desc traj;          /* RAPTOR_TRAJ_BEZIER, Nact = 12                                               */
@@ -164,6 +184,7 @@ typedef struct raptor_digit_desc {
     const double* joint_limits_upper;
     double mu, gamma, Lx, Ly;
     raptor_gait_desc gait;          /* fourth block: DigitCustomizedConstraints                                    */
+    raptor_period_desc period;      /* fifth block: DigitSingleStepPeriodicityConstraints (only `enabled` is read) */
 } raptor_digit_desc;
 
 typedef struct raptor_model raptor_model;     /* opaque */

@@ -1325,6 +1325,17 @@ int oracle_legged_problem_create(const raptor_model* model, const raptor_legged_
             &p.cid, false, d->stance_leg == 'L', d->gait.swing_joint_id,
             Transform(Vec3(d->gait.swingfoot_endT_p[0], d->gait.swingfoot_endT_p[1], d->gait.swingfoot_endT_p[2])), d->gait));
     }
+    if (d->period.enabled) {  // :101-106
+        const raptor_period_desc& pd = d->period;
+        if (pd.swing_contact_joint_id < 1 || pd.swing_contact_joint_id > nv) throw std::runtime_error("Can not find joint");
+        if (!pd.joint_id1 || !pd.joint_id2) throw std::invalid_argument("null argument");
+        std::vector<int> id1(pd.joint_id1, pd.joint_id1 + dc.ni), id2(pd.joint_id2, pd.joint_id2 + dc.ni);
+        for (int k = 0; k < dc.ni; k++)
+            if (id1[k] < 0 || id1[k] >= nv || id2[k] < 0 || id2[k] >= nv) throw std::runtime_error("Can not find joint");
+        p.cons.emplace_back(new PeriodicityConstraints(
+            &p.cid, d->mu, d->gamma, d->Lx, d->Ly, pd.mirror_sign, id1, id2, pd.swing_contact_joint_id,
+            Transform(Vec3(pd.swing_foot_endT_p[0], pd.swing_foot_endT_p[1], pd.swing_foot_endT_p[2]))));
+    }
     p.finish();
     *out = pr.release();
     ORACLE_CATCH
@@ -1435,6 +1446,21 @@ int oracle_digit_problem_create(const raptor_model* model, const raptor_digit_de
             for (int c = 0; c < 3; c++) Re(r, c) = R[3 * r + c];
         p.cons.emplace_back(new CustomizedConstraints(&p.cid, true, sleg == 0, d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1,
                                                       Transform(Re, Vec3(pp[0], pp[1], pp[2])), d->gait));
+    }
+    if (d->period.enabled) {  // :102-106; JOINT_MAP of DigitSingleStepPeriodicityConstraints.h:19-32
+        double R[9], pp[3];
+        digit_stance_foot_endT(1 - sleg, R, pp);  // DigitDynamicsConstraints.cpp:81-95 after the swap
+        Mat3 Re;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Re(r, c) = R[3 * r + c];
+        std::vector<int> id1, id2;
+        for (int leg = 0; leg < 2; leg++)
+            for (int k = 0; k < 6; k++) {
+                id1.push_back(d->leg_ids[leg][DIGIT_LEG_INDEPENDENT[k]]);
+                id2.push_back(d->leg_ids[1 - leg][DIGIT_LEG_INDEPENDENT[k]]);
+            }
+        p.cons.emplace_back(new PeriodicityConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly, 1.0, id1, id2,
+                                                       d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1, Transform(Re, Vec3(pp[0], pp[1], pp[2]))));
     }
     p.finish();
     *out = pr.release();

@@ -109,6 +109,34 @@ def _gait(cfg) -> "GaitDesc":
     return g
 
 
+class PeriodDesc(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int),
+        ("swing_contact_joint_id", C.c_int),
+        ("swing_foot_endT_p", C.c_double * 3),
+        ("joint_id1", _ip),
+        ("joint_id2", _ip),
+        ("mirror_sign", C.c_double),
+    ]
+
+
+def _period(cfg, keep: list) -> "PeriodDesc":
+    d = PeriodDesc()
+    pp = getattr(cfg, "period", None)
+    if pp is None:
+        return d
+    d.enabled = 1
+    d.swing_contact_joint_id = int(pp.get("swing_contact_joint_id", 0))
+    d.swing_foot_endT_p = (C.c_double * 3)(*[float(x) for x in pp.get("swing_foot_endT_p", (0, 0, 0))])
+    if "joint_id1" in pp:
+        a = np.ascontiguousarray(pp["joint_id1"], dtype=np.int32)
+        b = np.ascontiguousarray(pp["joint_id2"], dtype=np.int32)
+        keep += [a, b]
+        d.joint_id1, d.joint_id2 = a.ctypes.data_as(_ip), b.ctypes.data_as(_ip)
+    d.mirror_sign = float(pp.get("mirror_sign", -1.0))
+    return d
+
+
 class LeggedDesc(C.Structure):
     _fields_ = [
         ("traj", TrajDesc),
@@ -132,6 +160,7 @@ class LeggedDesc(C.Structure):
         ("Ly", C.c_double),
         ("stance_leg", C.c_int),
         ("gait", GaitDesc),
+        ("period", PeriodDesc),
     ]
 
 
@@ -153,6 +182,7 @@ class DigitDesc(C.Structure):
         ("Lx", C.c_double),
         ("Ly", C.c_double),
         ("gait", GaitDesc),
+        ("period", PeriodDesc),
     ]
 
 
@@ -389,6 +419,8 @@ class ProblemHandle:
         d.mu, d.gamma, d.Lx, d.Ly = float(cfg.mu), float(cfg.gamma), float(cfg.Lx), float(cfg.Ly)
         d.stance_leg = ord(getattr(cfg, "stance_leg", "L"))
         d.gait = _gait(cfg)
+        keep = []
+        d.period = _period(cfg, keep)
         h = C.c_void_p()
         api.check(api.fn("legged_problem_create")(model.handle, C.byref(d), C.byref(h)))
         return cls(api, h)
@@ -412,6 +444,8 @@ class ProblemHandle:
         d.joint_limits_lower, d.joint_limits_upper = _ptr(jl), _ptr(ju)
         d.mu, d.gamma, d.Lx, d.Ly = float(cfg.mu), float(cfg.gamma), float(cfg.Lx), float(cfg.Ly)
         d.gait = _gait(cfg)
+        keep = []
+        d.period = _period(cfg, keep)
         h = C.c_void_p()
         api.check(api.fn("digit_problem_create")(model.handle, C.byref(d), C.byref(h)))
         return cls(api, h)

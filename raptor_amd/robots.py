@@ -33,6 +33,7 @@ class LeggedConfig:
     N: int = 14
     stance_leg: str = "L"
     gait: Optional[dict] = None   # GaitParameters + swing foot (None: customized block left out)
+    period: Optional[dict] = None  # reset-map block (None: left out)
 
 
 # ---- Talos: Examples/Talos/include/TalosConstants.h:7-96, TalosDynamicsConstraints.h:14-36 ----
@@ -77,6 +78,14 @@ def talos_gait(m: RobotModel, stance_leg: str = "L") -> dict:
     return dict(swing_joint_id=m.joint_id(swing) + 1, swingfoot_endT_p=(0.0, 0.0, -0.107), eps_torso_angle=np.deg2rad(1.5),
                 swingfoot_midstep_z_des=0.10, swingfoot_begin_x_des=0.0, swingfoot_begin_y_des=-0.17, swingfoot_end_x_des=0.0,
                 swingfoot_end_y_des=-0.17, torso_height_lb=0.95)
+
+
+def talos_period(m: RobotModel, stance_leg: str = "L") -> dict:
+    """TalosSingleStepPeriodicityConstraints.h:19-32 JOINT_MAP, TalosDynamicsConstraints.cpp:44-62 reinitialize()."""
+    swing = "leg_right_6_joint" if stance_leg in "Ll" else "leg_left_6_joint"
+    id1 = [m.joint_id(n) for n in _TALOS_IND]
+    return dict(swing_contact_joint_id=m.joint_id(swing) + 1, swing_foot_endT_p=(0.0, 0.0, -0.107),
+                joint_id1=id1, joint_id2=id1[6:] + id1[:6], mirror_sign=-1.0)
 
 
 # ---- Unitree-G1: Examples/Unitree-G1/include/G1Constants.h, G1DynamicsConstraints.h:14-36, G1SingleStep.cpp:18-43 ----
@@ -138,6 +147,14 @@ def g1_gait(m: RobotModel, stance_leg: str = "L") -> dict:
                 swingfoot_end_y_des=-0.237013, torso_height_lb=0.55)
 
 
+def g1_period(m: RobotModel, stance_leg: str = "L") -> dict:
+    """G1SingleStepPeriodicityConstraints.h:19-32 JOINT_MAP, G1DynamicsConstraints.cpp reinitialize()."""
+    swing = "right_ankle_roll_joint" if stance_leg in "Ll" else "left_ankle_roll_joint"
+    id1 = [m.joint_id(n) for n in _G1_IND]
+    return dict(swing_contact_joint_id=m.joint_id(swing) + 1, swing_foot_endT_p=(0.035, 0.0, -0.03),
+                joint_id1=id1, joint_id2=id1[6:] + id1[:6], mirror_sign=-1.0)
+
+
 # ---- Digit-v3: Examples/Digit/include/DigitConstants.h, DigitDynamicsConstraints.h:19-57, DigitSingleStep.cpp:16-40 ----
 DIGIT_LEG_JOINTS = ["hip_roll", "hip_yaw", "hip_pitch", "achilles_rod", "ach2", "knee", "tarsus", "toe_A", "toe_A_rod",
                     "A2", "toe_B", "toe_B_rod", "B2", "toe_pitch", "toe_roll"]
@@ -172,6 +189,7 @@ class DigitConfig:
     T: float = 0.4
     N: int = 14
     gait: Optional[dict] = None   # GaitParameters (None: customized block left out)
+    period: Optional[dict] = None  # reset-map block: {} enables it (everything is derived from the stance leg)
 
     @property
     def independent_ids(self):

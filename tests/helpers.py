@@ -47,7 +47,7 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
-def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, customized=False):
+def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False):
     """Talos / Unitree-G1 single-step problem (TalosSingleStepOptimizer.cpp:17-124, G1 twin)."""
     import os
 
@@ -66,13 +66,15 @@ def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, 
         cfg.degree = degree
     if customized:
         cfg.gait = (robots.talos_gait if which == "talos" else robots.g1_gait)(m, stance)
+    if periodic:
+        cfg.period = (robots.talos_period if which == "talos" else robots.g1_period)(m, stance)
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV)
     return A.ProblemHandle.legged(api, mh, t, cfg), m, cfg
 
 
-def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customized=False):
+def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False):
     """Digit-v3 single-step problem (DigitSingleStepOptimizer.cpp:17-124)."""
     import os
 
@@ -87,6 +89,8 @@ def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customiz
         cfg.degree = degree
     if customized:
         cfg.gait = robots.digit_gait()
+    if periodic:
+        cfg.period = {}
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV)
