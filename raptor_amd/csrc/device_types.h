@@ -100,6 +100,7 @@ struct DevLegged {
     int sf_body;                              // body that carries the swing foot
     double sf_R[9], sf_p[3];                  // swing-foot end transform
     int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
+    int nperiod, off_period;                  // reset-map block (period_kernel.h): rows (0: absent), offset
     // per-sample-eval record written by the core kernel (doubles):
     //   tau[ni] lambda[6] q[nv] v[nv] a[nv] | D[it][x][ni] (x = q, v, a; rows = actuators) | L[it][x][6] |
     //   Pb[it][6] (floating-base rows of P_dep) | Pl[nd - 6][2] (closed-loop rows of P_dep, columns dep_col)
@@ -111,6 +112,32 @@ struct DevLegged {
 struct DevCustRow {
     int sample, qa, qb, wrap;
     double ca, cb, add;
+};
+
+// Reset-map ("periodicity") block, period_kernel.h.  The model's own tree (rooted at the world, floating-base joints
+// included) in DFS pre-order: lane = joint = the link it moves, subtree(g) = [g, end[g]).
+#define RAPTOR_PERIOD_MAX_LOOPS 4
+struct DevPeriod {
+    int nj;                                   // joints (= model nv)
+    int off;                                  // first row of the block in Optimizer order
+    int lane_joint[64];                       // lane -> model joint
+    int joint_lane[RAPTOR_MAX_NV];
+    int end[64], depth[64];
+    int path[64][RAPTOR_LEG_MAX_DEPTH];       // lanes from the root down to and including this one
+    int old_foot_lane, new_foot_lane;         // stance foot of the step, stance foot after the swap
+    double endR[9], endp[3];                  // stance_foot_endT after the swap
+    int id1[RAPTOR_LEG_MAX_IND], id2[RAPTOR_LEG_MAX_IND];  // JOINT_MAP as model joints
+    double sign;                              // g3 = q_0(id1) + sign * q_minus(id2)
+    // closed loops (Digit): loop l = leg * 2 + (0: knee, 1: toe); per decision vector a record
+    //   J[nr][nvl] | J v+ [nr] | J^T lambda [nvl] | D(J v+)[nr][nx] | D(J^T lambda)[nvl][nx]      (digit_period_loops_kernel)
+    int nloops, loop_stride;
+    int loop_nvl[RAPTOR_PERIOD_MAX_LOOPS], loop_nr[RAPTOR_PERIOD_MAX_LOOPS], loop_nx[RAPTOR_PERIOD_MAX_LOOPS];
+    int loop_row0[RAPTOR_PERIOD_MAX_LOOPS];   // first constraint row (= first lambda entry) of the loop
+    int loop_col[RAPTOR_PERIOD_MAX_LOOPS][2]; // minimal columns of its drivers
+    int loop_off[RAPTOR_PERIOD_MAX_LOOPS];    // offset of its record
+    int joint_loop[RAPTOR_MAX_NV], joint_var[RAPTOR_MAX_NV];  // model joint -> loop / local variable (-1: none)
+    int joint_rec[RAPTOR_MAX_NV];             // dependent loop joint -> its record in the per-sample loop buffer
+    int row_loop[24], row_local[24];          // closure row -> loop / row inside the loop
 };
 
 // where each constraint block of this problem starts in the Optimizer's row order (-1: block absent)

@@ -36,6 +36,8 @@ struct DevLoop {
     DevClosure cl[2];
     int drv_traj[2];   // trajectory index of the driving joints
     int rec0;          // first dependent-joint record of this loop in the per-sample loop buffer
+    int var_joint[8];  // model joint of each local variable
+    int row0;          // first row of the loop's closures in the reference's constraint order (DigitDynamicsConstraints.cpp:579-596)
     double g_sign[6], g_c0[6], g_lin[6][8], g_pair[6][16];  // initial guess (digit_tables.h)
 };
 struct DevDigit {

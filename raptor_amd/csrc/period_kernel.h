@@ -1,0 +1,503 @@
+// K_period : the reset-map ("periodicity") block of the single-step optimizers
+// (Examples/Digit/src/DigitSingleStepPeriodicityConstraints.cpp:57-215, Examples/Talos/src/
+// TalosSingleStepPeriodicityConstraints.cpp:57-215, Unitree-G1 twin):
+//   g1 = H(q-) (v+ - v-) - J(q-)^T lambda      g2 = J(q-) v+      g3, g4 position / velocity reset      g5 contact on lambda
+// with q-, v- the last sample of the step, J the constraint Jacobian after the stance swap, v+ and lambda taken from z.
+//
+// MI355X design -- NOT the reference's algorithm order.  The reference forms crba(q-), J, the tensors Jx_partial_dq and
+// JTx_partial_dq, a gravity-free computeRNEADerivatives and multiplies by pq_pz(last), pv_pz(last) (nv x varLength).
+// Only 12 directions matter: along actuator t the robot moves on the stance-phase manifold with joint rates
+// u = Pfull[:, t] (already in the core kernel's record).  With w_l the world-frame twist of body l per unit q_t,
+//     D_t s_k = w_k x s_k      D_t (I_l a) = w_l x* (I_l a) - I_l (w_l x a) + I_l D_t a      D_t p_c = w_foot at p_c
+// so every term of D_t g1, D_t g2 is a path walk plus a subtree sum, and d v-/d q_t needs no J_dep^-1: the planted foot
+// stays planted, sum_base s_b Vq_b = -(sum over the old stance foot's path of (w_j x s_j) v-_j + s_j Vq_j).
+// One wavefront per decision vector, lane = joint of the model's own tree in DFS pre-order (subtree = lane range,
+// composites by wave shuffles); the block's rows are assembled in LDS pieces and streamed out densely.
+// numpy model: scripts/proto_period.py (agrees with the oracle's literal restatement to 5e-14).
+#ifndef RAPTOR_PERIOD_KERNEL_H
+#define RAPTOR_PERIOD_KERNEL_H
+
+#include "digit_kernel.h"
+#include "legged_kernel.h"
+
+// LDS map of legged_period_kernel (doubles)
+#define PL_LOC 0                                   // [nv][16] local joint transform: X (9), t (3), axis (3), prismatic flag
+#define PL_S (PL_LOC + RAPTOR_MAX_NV * 16)         // [nv][6] world-frame joint axes, by lane
+#define PL_DV (PL_S + RAPTOR_MAX_NV * 6)           // by lane: v+ - v-, v+, v-, u (direction), Vq (direction)
+#define PL_VP (PL_DV + RAPTOR_MAX_NV)
+#define PL_VM (PL_VP + RAPTOR_MAX_NV)
+#define PL_U (PL_VM + RAPTOR_MAX_NV)
+#define PL_VQ (PL_U + RAPTOR_MAX_NV)
+#define PL_H (PL_VQ + RAPTOR_MAX_NV)               // [nv][nv] crba(q-) incl. armature, by model joint
+#define PL_JA (PL_H + RAPTOR_MAX_NV * RAPTOR_MAX_NV)  // [nd][nv] constraint Jacobian after the swap
+#define PL_D1 (PL_JA + 24 * RAPTOR_MAX_NV)         // [nv][ni] coefficient of B_k(T) in the g1 rows
+#define PL_D2 (PL_D1 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nv][ni] coefficient of dB_k(T)
+#define PL_G2 (PL_D2 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nd][ni] D_t (J v+)
+#define PL_W (PL_G2 + 24 * RAPTOR_LEG_MAX_IND)     // [4][16] B, dB of the first sample, B, dB of the last
+#define PL_C5 (PL_W + 64)                          // [7][6] d g5 / d lambda.tail(6)
+#define PL_TOTAL (PL_C5 + 42)
+
+// directional derivative of rpy_rates(R, w) with respect to R along dR = [ww]x R (w fixed): the second-order part of
+// ForwardKinematicsSolver::getRPYHessian (ForwardKinematics.cpp:445-498)
+RD V3 d_rpy_rates(const M3& R, V3 w, V3 ww) {
+    const V3 c0 = col(R, 0), c1 = col(R, 1), c2 = col(R, 2);
+    const V3 d0 = cross(w, c0), d1 = cross(w, c1), d2 = cross(w, c2);        // dR = [w]x R, by column
+    const V3 v0 = cross(ww, c0), v1 = cross(ww, c1), v2 = cross(ww, c2);     // variation of R
+    const V3 e0 = cross(w, v0), e1 = cross(w, v1), e2 = cross(w, v2);        // variation of dR
+    // roll = atan2(-R12, R22): entries (1,2) = c2.y, (2,2) = c2.z
+    const double D0 = c2.y * c2.y + c2.z * c2.z;
+    const double N0 = c2.y * d2.z - c2.z * d2.y;
+    const double vN0 = v2.y * d2.z + c2.y * e2.z - v2.z * d2.y - c2.z * e2.y;
+    const double vD0 = 2.0 * (c2.y * v2.y + c2.z * v2.z);
+    // yaw = atan2(-R01, R00): entries (0,0) = c0.x, (0,1) = c1.x
+    const double D2 = c0.x * c0.x + c1.x * c1.x;
+    const double N2 = c1.x * d0.x - c0.x * d1.x;
+    const double vN2 = v1.x * d0.x + c1.x * e0.x - v0.x * d1.x - c0.x * e1.x;
+    const double vD2 = 2.0 * (c0.x * v0.x + c1.x * v1.x);
+    // pitch = asin(R02): entry (0,2) = c2.x
+    const double x = c2.x;
+    const double om = 1.0 - x * x;
+    const double da = safe_dasin(x);
+    const double dda = (x >= 1.0 || x <= -1.0) ? 0.0 : x / (om * sqrt(om));
+    return v3((vN0 * D0 - N0 * vD0) / (D0 * D0), dda * v2.x * d2.x + da * e2.x, (vN2 * D2 - N2 * vD2) / (D2 * D2));
+}
+
+// Closed loops of Digit at q-: one lane per (decision vector, leg).  Writes, for its loop, the closure rows of J, J v+,
+// J^T lambda and their derivatives along the loop's own drivers (the only directions that move the loop).
+template <bool TOE>
+__global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+                                                                const DevPeriod* __restrict__ P,
+                                                                const double* __restrict__ basis, const int n, const int nv,
+                                                                const int nd, const double* __restrict__ Z,
+                                                                const long long total, const double* __restrict__ loops,
+                                                                double* __restrict__ ploops) {
+    constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NVL = NY + NX;
+    const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (w >= total) return;
+    const int leg = (int)(w & 1);
+    const long long b = w >> 1;
+    const int N = T->N;
+    const double* z = Z + b * n;
+    const DevLoop* L = &D->loop[leg][TOE ? 1 : 0];
+    const int l = leg * 2 + (TOE ? 1 : 0);
+    const double* lrec = loops + ((size_t)(b * N + N - 1) * D->recs_per_sample + L->rec0) * DIGIT_REC;
+
+    double th[NVL], vp[NVL], lam[NY], Y1[NX][NY];
+    {
+        double qd, qdd;
+        traj_joint(T, basis, z, N - 1, L->drv_traj[0], th[NY], qd, qdd);
+        if (TOE) traj_joint(T, basis, z, N - 1, L->drv_traj[1], th[NY + 1], qd, qdd);
+    }
+#pragma unroll
+    for (int r = 0; r < NY; r++) {
+        th[r] = lrec[r * DIGIT_REC];
+        Y1[0][r] = lrec[r * DIGIT_REC + 1];
+        if (TOE) Y1[NX - 1][r] = lrec[r * DIGIT_REC + 2];
+        lam[r] = z[n - nd + L->row0 + r];
+    }
+#pragma unroll
+    for (int k = 0; k < NVL; k++) vp[k] = z[n - nv - nd + L->var_joint[k]];
+
+    LoopSolver<NY, NX, NCL, NA, NB> S;
+    S.L = L;
+    S.geometry(th);
+    double Jm[NY][NVL];
+    S.jacobian(Jm);
+    double* out = ploops + (size_t)b * P->loop_stride + P->loop_off[l];
+#pragma unroll
+    for (int r = 0; r < NY; r++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NVL; k++) {
+            out[r * NVL + k] = Jm[r][k];
+            s += Jm[r][k] * vp[k];
+        }
+        out[NY * NVL + r] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < NVL; k++) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < NY; r++) s += Jm[r][k] * lam[r];
+        out[NY * NVL + NY + k] = s;
+    }
+    double* oDJv = out + NY * NVL + NY + NVL;
+    double* oDJTl = oDJv + NY * NX;
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        double U[NVL];
+#pragma unroll
+        for (int r = 0; r < NY; r++) U[r] = Y1[x][r];
+#pragma unroll
+        for (int xx = 0; xx < NX; xx++) U[NY + xx] = (xx == x) ? 1.0 : 0.0;
+        double d[NY];
+#pragma unroll
+        for (int r = 0; r < NY; r++) d[r] = 0.0;
+        S.add_D2(vp, U, d);
+#pragma unroll
+        for (int r = 0; r < NY; r++) oDJv[r * NX + x] = d[r];
+#pragma unroll 1
+        for (int k = 0; k < NVL; k++) {
+            double ek[NVL], dk[NY];
+#pragma unroll
+            for (int j = 0; j < NVL; j++) ek[j] = (j == k) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < NY; r++) dk[r] = 0.0;
+            S.add_D2(ek, U, dk);
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < NY; r++) s += lam[r] * dk[r];
+            oDJTl[k * NX + x] = s;
+        }
+    }
+}
+
+template <bool DERIV>
+__global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+                                                           const DevLegged* __restrict__ Q, const DevPeriod* __restrict__ P,
+                                                           const double* __restrict__ basis, const DevLayout L,
+                                                           const double* __restrict__ Z, const double* __restrict__ core,
+                                                           const double* __restrict__ loops,
+                                                           const double* __restrict__ ploops, double* __restrict__ G,
+                                                           double* __restrict__ JAC) {
+    extern __shared__ double lds[];
+    const int g = threadIdx.x;
+    const long long b = blockIdx.x;
+    const int nj = P->nj, ni = Q->ni, nd = Q->nd, nv = Q->nv, K = Q->K, n = L.n, N = T->N;
+    const int ncl = nd - 6;  // closure rows
+    const double* z = Z + b * n;
+    const double* rec0 = core + (size_t)(b * N) * Q->c_stride;
+    const double* recN = core + (size_t)(b * N + N - 1) * Q->c_stride;
+    const double* pl = (P->nloops > 0) ? ploops + (size_t)b * P->loop_stride : nullptr;
+    const int cv = n - nv - nd, cl = n - nd;
+    const size_t rowbase = (size_t)b * L.m + P->off;
+    const bool on = g < nj;
+    const int gj = on ? g : 0;
+    const int jnt = P->lane_joint[gj];
+    const int gend = on ? P->end[gj] : g;
+    const int depth = on ? P->depth[gj] : 0;
+    const int nf = P->new_foot_lane, of = P->old_foot_lane;
+    const double arm = on ? M->armature[jnt] : 0.0;
+    const int myloop = on ? P->joint_loop[jnt] : -1;
+    const int myvar = on ? P->joint_var[jnt] : 0;
+    const double* mypl = (myloop >= 0) ? pl + P->loop_off[myloop] : nullptr;
+    const int mynvl = (myloop >= 0) ? P->loop_nvl[myloop] : 0, mynr = (myloop >= 0) ? P->loop_nr[myloop] : 0,
+              mynx = (myloop >= 0) ? P->loop_nx[myloop] : 0;
+
+    // ---- phase 0: this joint's local transform at q-, the reset velocities; clear the sparse pieces ----
+    for (int k = g; k < RAPTOR_MAX_NV * RAPTOR_MAX_NV + 24 * RAPTOR_MAX_NV; k += 64) lds[PL_H + k] = 0.0;  // H and JA are adjacent
+    for (int k = g; k < 24 * RAPTOR_LEG_MAX_IND; k += 64) lds[PL_G2 + k] = 0.0;
+    const double qm = on ? recN[Q->c_q + jnt] : 0.0;
+    const double vm = on ? recN[Q->c_v + jnt] : 0.0;
+    const double vpl = on ? z[cv + jnt] : 0.0;
+    const double dvj = vpl - vm;
+    if (on) {
+        double sq, cq;
+        sincos(qm, &sq, &cq);
+        M3 Pm, X;
+#pragma unroll
+        for (int k = 0; k < 9; k++) Pm.m[k] = M->plR[jnt][k];
+        V3 o = v3(M->plp[jnt][0], M->plp[jnt][1], M->plp[jnt][2]);
+        SV sj;
+        joint_world(M->jtype[jnt], qm, cq, sq, Pm, X, o, sj);
+        const int jt = M->jtype[jnt];
+        const bool prism = jt > 3 || jt < -3;
+        const V3 ax = prism ? sj.l : sj.a;
+        double* x = lds + PL_LOC + g * 16;
+#pragma unroll
+        for (int k = 0; k < 9; k++) x[k] = X.m[k];
+        x[9] = o.x; x[10] = o.y; x[11] = o.z;
+        x[12] = ax.x; x[13] = ax.y; x[14] = ax.z;
+        x[15] = prism ? 1.0 : 0.0;
+        lds[PL_DV + g] = dvj;
+        lds[PL_VP + g] = vpl;
+        lds[PL_VM + g] = vm;
+    }
+    wave_sync();
+
+    // ---- phase A: world-frame pose and joint axis (walk from the world down to this joint) ----
+    M3 Rw;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 ow = v3(0, 0, 0);
+    SV s = sv_zero();
+#pragma unroll 1
+    for (int d = 0; d < depth; d++) {
+        const double* x = lds + PL_LOC + P->path[gj][d] * 16;
+        const M3 R = mul(Rw, x);
+        const V3 o = ow + mul(Rw, v3(x[9], x[10], x[11]));
+        const V3 axw = mul(Rw, v3(x[12], x[13], x[14]));
+        s = (x[15] != 0.0) ? SV{v3(0, 0, 0), axw} : SV{axw, cross(o, axw)};
+        Rw = R;
+        ow = o;
+    }
+    if (on) lds_put(lds + PL_S + g * 6, s);
+    InertiaO I;
+    {
+        Inertia Ic;
+        const V3 c = ow + mul(Rw, v3(M->lever[jnt][0], M->lever[jnt][1], M->lever[jnt][2]));
+        rotate_inertia(Rw, M->Ic[jnt], Ic);
+        const double m = on ? M->mass[jnt] : 0.0;
+        const double keep = on ? 1.0 : 0.0;
+        I.m = m;
+        I.hv = c * m;
+        const double cc = dot(c, c);
+        I.xx = keep * Ic.xx + m * (cc - c.x * c.x);
+        I.yy = keep * Ic.yy + m * (cc - c.y * c.y);
+        I.zz = keep * Ic.zz + m * (cc - c.z * c.z);
+        I.xy = keep * Ic.xy - m * c.x * c.y;
+        I.xz = keep * Ic.xz - m * c.x * c.z;
+        I.yz = keep * Ic.yz - m * c.y * c.z;
+    }
+    wave_sync();
+
+    // ---- phase B: values.  a = sum s_j (v+ - v-)_j, V+ = sum s_j v+_j along the path; contact point after the swap ----
+    SV aD = sv_zero(), Vp = sv_zero();
+#pragma unroll 1
+    for (int d = 0; d < depth; d++) {
+        const int j = P->path[gj][d];
+        const SV sj = lds_sv(lds + PL_S + j * 6);
+        aD = aD + sj * lds[PL_DV + j];
+        Vp = Vp + sj * lds[PL_VP + j];
+    }
+    M3 Rc;
+    V3 pc;
+    {
+        const M3 Rmine = mul(Rw, P->endR);
+        const V3 pmine = ow + mul(Rw, v3(P->endp[0], P->endp[1], P->endp[2]));
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rc.m[k] = __shfl(Rmine.m[k], nf, 64);
+        pc = v3(__shfl(pmine.x, nf, 64), __shfl(pmine.y, nf, 64), __shfl(pmine.z, nf, 64));
+    }
+    const V3 lt = v3(z[cl + nd - 6], z[cl + nd - 5], z[cl + nd - 4]);
+    const V3 lr = v3(z[cl + nd - 3], z[cl + nd - 2], z[cl + nd - 1]);
+    const SV Ia = applyO(I, aD);
+    SV f = Ia;
+    if (g == nf) {  // - J_foot^T lambda.tail(6) is a wrench at the contact point: [p_c x f + E^T m ; f]
+        const V3 Etl = v3(dot(lr, rpy_rates(Rc, v3(1, 0, 0))), dot(lr, rpy_rates(Rc, v3(0, 1, 0))), dot(lr, rpy_rates(Rc, v3(0, 0, 1))));
+        f = f - SV{cross(pc, lt) + Etl, lt};
+    }
+    SV F = f;
+    InertiaO IC = I;
+    const int src = gend & 63;
+#define SCAN(x) { const double y_ = __shfl_down(x, d, 64); if (take) x += y_; }
+#define CUT(x) { const double y_ = __shfl(x, src, 64); x -= y_; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const bool take = (g + d) < 64;
+        SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
+        SCAN(IC.m) SCAN(IC.hv.x) SCAN(IC.hv.y) SCAN(IC.hv.z)
+        SCAN(IC.xx) SCAN(IC.xy) SCAN(IC.xz) SCAN(IC.yy) SCAN(IC.yz) SCAN(IC.zz)
+    }
+    CUT(F.a.x) CUT(F.a.y) CUT(F.a.z) CUT(F.l.x) CUT(F.l.y) CUT(F.l.z)
+    CUT(IC.m) CUT(IC.hv.x) CUT(IC.hv.y) CUT(IC.hv.z)
+    CUT(IC.xx) CUT(IC.xy) CUT(IC.xz) CUT(IC.yy) CUT(IC.yz) CUT(IC.zz)
+
+    if (on) {
+        // (1) H (v+ - v-) - J^T lambda   (:88-98)
+        double val = dot(s, F) + arm * dvj;
+        if (myloop >= 0) val -= mypl[mynr * mynvl + mynr + myvar];
+        if (G != nullptr) G[rowbase + jnt] = val;
+        // crba(q-): H_kc = s_c . I^C_k s_k for c on the path of k   (:89-96; armature on the diagonal as Pinocchio >= 3 has it)
+        const SV IS = applyO(IC, s);
+#pragma unroll 1
+        for (int d = 0; d < depth; d++) {
+            const int c = P->path[gj][d];
+            const int jc = P->lane_joint[c];
+            const double h = dot(lds_sv(lds + PL_S + c * 6), IS) + ((c == g) ? arm : 0.0);
+            lds[PL_H + jnt * nv + jc] = h;
+            lds[PL_H + jc * nv + jnt] = h;
+        }
+        // stance-foot rows of J after the swap (TalosDynamicsConstraints.cpp:264-279): translation and RPY Jacobian columns
+        if (g <= nf && nf < gend) {
+            const V3 Jt = s.l + cross(s.a, pc);
+            const V3 Jr = rpy_rates(Rc, s.a);
+            double* ja = lds + PL_JA + ncl * nv + jnt;
+            ja[0] = Jt.x; ja[nv] = Jt.y; ja[2 * nv] = Jt.z;
+            ja[3 * nv] = Jr.x; ja[4 * nv] = Jr.y; ja[5 * nv] = Jr.z;
+        }
+        // closure rows of J (Digit): columns of the loop joints only
+        if (myloop >= 0) {
+            const int row0 = P->loop_row0[myloop];
+            for (int r = 0; r < mynr; r++) lds[PL_JA + (row0 + r) * nv + jnt] = mypl[r * mynvl + myvar];
+        }
+    }
+    if (G != nullptr) {
+        // (2) J v+   (:119-120)
+        if (g == nf) {
+            const V3 lin = Vp.l + cross(Vp.a, pc);
+            const V3 rot = rpy_rates(Rc, Vp.a);
+            double* o = G + rowbase + nv + ncl;
+            o[0] = lin.x; o[1] = lin.y; o[2] = lin.z; o[3] = rot.x; o[4] = rot.y; o[5] = rot.z;
+        }
+        if (g < ncl) {
+            const int l = P->row_loop[g];
+            G[rowbase + nv + g] = pl[P->loop_off[l] + P->loop_nr[l] * P->loop_nvl[l] + P->row_local[g]];
+        }
+        // (3) position reset, (4) velocity reset   (:130-144)
+        if (g < ni) {
+            const int a = P->id1[g], c = P->id2[g];
+            G[rowbase + nv + nd + g] = rec0[Q->c_q + a] + P->sign * recN[Q->c_q + c];
+            G[rowbase + nv + nd + ni + g] = rec0[Q->c_v + a] + P->sign * z[cv + c];
+        }
+        // (5) contact constraints on the impact impulse   (:152-179)
+        if (g == 0) {
+            double* o = G + rowbase + nv + nd + 2 * ni;
+            const double fz = lt.z;
+            o[0] = fz;
+            o[1] = lt.x * lt.x + lt.y * lt.y - (Q->mu * fz) * (Q->mu * fz);
+            o[2] = lr.z * lr.z - (Q->gamma * fz) * (Q->gamma * fz);
+            o[3] = lr.x - Q->Lx * fz;
+            o[4] = -Q->Lx * fz - lr.x;
+            o[5] = lr.y - Q->Ly * fz;
+            o[6] = -Q->Ly * fz - lr.y;
+        }
+    }
+    if (!DERIV) return;
+
+    // ---- phase C: the twelve manifold directions ----
+#pragma unroll 1
+    for (int t = 0; t < ni; t++) {
+        {   // this joint's rate along the direction, and d v-/d q_t of a closed-loop joint (Y2 contracted with the drivers' rates)
+            double u = 0.0, vq = 0.0;
+            if (on) {
+                const int ti = Q->joint_ind[jnt], dd = Q->joint_dep[jnt];
+                if (ti >= 0) u = (ti == t) ? 1.0 : 0.0;
+                else if (dd < 6) u = recN[Q->c_P + t * 6 + dd];
+                else {
+                    const int c0 = Q->dep_col[dd][0], c1 = Q->dep_col[dd][1];
+                    const double* p2 = recN + Q->c_Pl + (dd - 6) * 2;
+                    u = (t == c0) ? p2[0] : ((t == c1) ? p2[1] : 0.0);
+                    const double* y = loops + ((size_t)(b * N + N - 1) * Q->nrec + P->joint_rec[jnt]) * DIGIT_REC;
+                    const double va = recN[Q->c_v + Q->ind_joint[c0]];
+                    const double vb = (c1 >= 0) ? recN[Q->c_v + Q->ind_joint[c1]] : 0.0;
+                    if (t == c0) vq = y[3] * va + y[4] * vb;
+                    else if (t == c1) vq = y[4] * va + y[5] * vb;
+                }
+                lds[PL_U + g] = u;
+                lds[PL_VQ + g] = vq;
+            }
+        }
+        wave_sync();
+        SV w = sv_zero(), CD = sv_zero(), Cp = sv_zero(), Cm = sv_zero(), Sq = sv_zero();
+#pragma unroll 1
+        for (int d = 0; d < depth; d++) {
+            const int j = P->path[gj][d];
+            const SV sj = lds_sv(lds + PL_S + j * 6);
+            w = w + sj * lds[PL_U + j];
+            const SV c = crm(w, sj);
+            CD = CD + c * lds[PL_DV + j];
+            Cp = Cp + c * lds[PL_VP + j];
+            Cm = Cm + c * lds[PL_VM + j];
+            Sq = Sq + sj * lds[PL_VQ + j];
+        }
+        // the old stance foot stays planted along the direction: sum_base s_b Vq_b = -(Cm + Sq) at its lane
+        SV rof = Cm + Sq;
+        rof.a.x = __shfl(rof.a.x, of, 64); rof.a.y = __shfl(rof.a.y, of, 64); rof.a.z = __shfl(rof.a.z, of, 64);
+        rof.l.x = __shfl(rof.l.x, of, 64); rof.l.y = __shfl(rof.l.y, of, 64); rof.l.z = __shfl(rof.l.z, of, 64);
+        const SV da = CD - Sq + rof;
+        SV df = crf(w, Ia) - applyO(I, crm(w, aD)) + applyO(I, da);
+        const V3 dpc = w.l + cross(w.a, pc);  // meaningful on the new stance foot's lane
+        if (g == nf) {
+            const V3 dEtl = v3(dot(lr, d_rpy_rates(Rc, v3(1, 0, 0), w.a)), dot(lr, d_rpy_rates(Rc, v3(0, 1, 0), w.a)),
+                               dot(lr, d_rpy_rates(Rc, v3(0, 0, 1), w.a)));
+            df = df - SV{cross(dpc, lt) + dEtl, v3(0, 0, 0)};
+        }
+        SV dF = on ? df : sv_zero();
+        SV FP = on ? applyO(I, w) : sv_zero();
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const bool take = (g + d) < 64;
+            SCAN(dF.a.x) SCAN(dF.a.y) SCAN(dF.a.z) SCAN(dF.l.x) SCAN(dF.l.y) SCAN(dF.l.z)
+            SCAN(FP.a.x) SCAN(FP.a.y) SCAN(FP.a.z) SCAN(FP.l.x) SCAN(FP.l.y) SCAN(FP.l.z)
+        }
+        CUT(dF.a.x) CUT(dF.a.y) CUT(dF.a.z) CUT(dF.l.x) CUT(dF.l.y) CUT(dF.l.z)
+        CUT(FP.a.x) CUT(FP.a.y) CUT(FP.a.z) CUT(FP.l.x) CUT(FP.l.y) CUT(FP.l.z)
+        if (on) {
+            double d1 = dot(crm(w, s), F) + dot(s, dF) - arm * lds[PL_VQ + g];
+            if (myloop >= 0) {
+                const double* dj = mypl + mynr * mynvl + mynr + mynvl + mynr * mynx + myvar * mynx;
+                if (t == P->loop_col[myloop][0]) d1 -= dj[0];
+                else if (mynx > 1 && t == P->loop_col[myloop][1]) d1 -= dj[1];
+            }
+            lds[PL_D1 + jnt * ni + t] = d1;
+            lds[PL_D2 + jnt * ni + t] = -(dot(s, FP) + arm * lds[PL_U + g]);
+        }
+        if (g == nf) {  // D_t (J_foot v+)
+            const V3 lin = Cp.l + cross(Cp.a, pc) + cross(Vp.a, dpc);
+            const V3 rot = d_rpy_rates(Rc, Vp.a, w.a) + rpy_rates(Rc, Cp.a);
+            double* o = lds + PL_G2 + ncl * ni + t;
+            o[0] = lin.x; o[ni] = lin.y; o[2 * ni] = lin.z; o[3 * ni] = rot.x; o[4 * ni] = rot.y; o[5 * ni] = rot.z;
+        }
+        if (g < ncl) {  // D_t (J_closure v+): only the loop's own drivers move it
+            const int l = P->row_loop[g];
+            const int nx = P->loop_nx[l];
+            const double* dj = pl + P->loop_off[l] + P->loop_nr[l] * P->loop_nvl[l] + P->loop_nr[l] + P->loop_nvl[l] + P->row_local[g] * nx;
+            if (t == P->loop_col[l][0]) lds[PL_G2 + g * ni + t] = dj[0];
+            else if (nx > 1 && t == P->loop_col[l][1]) lds[PL_G2 + g * ni + t] = dj[1];
+        }
+        wave_sync();
+    }
+#undef SCAN
+#undef CUT
+
+    // ---- phase D: Bernstein weights of the first and last sample, d g5, then the dense rows ----
+    if (g < K) {
+        lds[PL_W + g] = basis[g];                                 // B_k(t_0)
+        lds[PL_W + 16 + g] = basis[K + g];                        // dB_k(t_0)
+        lds[PL_W + 32 + g] = basis[(size_t)((N - 1) * 3) * K + g];      // B_k(t_N-1)
+        lds[PL_W + 48 + g] = basis[(size_t)((N - 1) * 3 + 1) * K + g];  // dB_k(t_N-1)
+    }
+    if (g < 42) {  // d g5 / d lambda.tail(6)   (:181-204)
+        const int r = g / 6, c = g - r * 6;
+        const double fz = lt.z, mu = Q->mu, gam = Q->gamma;
+        double val = 0.0;
+        switch (r) {
+            case 0: val = (c == 2) ? 1.0 : 0.0; break;
+            case 1: val = (c == 0) ? 2.0 * lt.x : ((c == 1) ? 2.0 * lt.y : ((c == 2) ? -2.0 * mu * mu * fz : 0.0)); break;
+            case 2: val = (c == 5) ? 2.0 * lr.z : ((c == 2) ? -2.0 * gam * gam * fz : 0.0); break;
+            case 3: val = (c == 3) ? 1.0 : ((c == 2) ? -Q->Lx : 0.0); break;
+            case 4: val = (c == 3) ? -1.0 : ((c == 2) ? -Q->Lx : 0.0); break;
+            case 5: val = (c == 4) ? 1.0 : ((c == 2) ? -Q->Ly : 0.0); break;
+            default: val = (c == 4) ? -1.0 : ((c == 2) ? -Q->Ly : 0.0); break;
+        }
+        lds[PL_C5 + g] = val;
+    }
+    wave_sync();
+    const int ndyn = ni * K;
+    const int mp = nv + nd + 2 * ni + 7;
+    double* out = JAC + rowbase * n;
+    const int total = mp * n;
+    int r = g / n, c = g - r * n;
+    const int dr = 64 / n, dc = 64 - dr * n;
+    for (int idx = g; idx < total; idx += 64) {
+        double val = 0.0;
+        const bool dyn = c < ndyn;
+        const int t = dyn ? c / K : 0, k = dyn ? c - t * K : 0;
+        if (r < nv) {  // pg1_pz (:114-116)
+            if (dyn) val = lds[PL_D1 + r * ni + t] * lds[PL_W + 32 + k] + lds[PL_D2 + r * ni + t] * lds[PL_W + 48 + k];
+            else if (c >= cl) val = -lds[PL_JA + (c - cl) * nv + r];
+            else if (c >= cv) val = lds[PL_H + r * nv + (c - cv)];
+        } else if (r < nv + nd) {  // pg2_pz (:126-127)
+            const int d = r - nv;
+            if (dyn) val = lds[PL_G2 + d * ni + t] * lds[PL_W + 32 + k];
+            else if (c >= cv && c < cl) val = lds[PL_JA + d * nv + (c - cv)];
+        } else if (r < nv + nd + ni) {  // pg3_pz (:137)
+            const int i = r - nv - nd;
+            if (dyn) val = ((t == Q->joint_ind[P->id1[i]]) ? lds[PL_W + k] : 0.0) + ((t == Q->joint_ind[P->id2[i]]) ? P->sign * lds[PL_W + 32 + k] : 0.0);
+        } else if (r < nv + nd + 2 * ni) {  // pg4_pz (:148)
+            const int i = r - nv - nd - ni;
+            if (dyn) val = (t == Q->joint_ind[P->id1[i]]) ? lds[PL_W + 16 + k] : 0.0;
+            else if (c >= cv && c < cl) val = (c - cv == P->id2[i]) ? P->sign : 0.0;
+        } else {  // pg5_pz
+            const int i = r - nv - nd - 2 * ni;
+            if (c >= n - 6) val = lds[PL_C5 + i * 6 + (c - (n - 6))];
+        }
+        out[idx] = val;
+        r += dr;
+        c += dc;
+        if (c >= n) { c -= n; r++; }
+    }
+}
+
+#endif

@@ -18,6 +18,7 @@
 #include "kinova_kernel.h"
 #include "legged_kernel.h"
 #include "digit_kernel.h"
+#include "period_kernel.h"
 #include "digit_constants.h"
 #include "digit_tables.h"
 
@@ -104,6 +105,10 @@ struct raptor_problem {
     DevBuf<int> d_kinds;
     DevBuf<DevCustRow> d_cust;       // customized block: row specs by row, per-sample row lists
     DevBuf<int> d_cust_list, d_cust_start;
+    bool has_period = false;         // reset-map block (period_kernel.h)
+    DevPeriod hper;
+    DevBuf<DevPeriod> d_per;
+    DevBuf<double> s_ploops;         // per-z closed-loop records of the reset-map block (Digit)
     DevModel hmodel;
     DevTraj htraj;
     DevSpheres hspheres;
@@ -345,6 +350,27 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
 void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
                    hipEvent_t between) {
     launch_legged_core(p, dZ, B, dG, jac, st);
+    if (p.has_period && B > 0) {  // reset-map block: once per decision vector, from the first and last samples' records
+        const double* d_pl = nullptr;
+        if (p.has_digit) {
+            p.s_ploops.ensure((size_t)B * p.hper.loop_stride);
+            const long long total = (long long)B * 2;
+            const unsigned lgrid = (unsigned)((total + 63) / 64);
+            hipLaunchKernelGGL((digit_period_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
+                               p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
+            hipLaunchKernelGGL((digit_period_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
+                               p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
+            d_pl = p.s_ploops.p;
+        }
+        const size_t plds = (size_t)PL_TOTAL * sizeof(double);
+        if (jac)
+            hipLaunchKernelGGL((legged_period_kernel<true>), dim3((unsigned)B), dim3(64), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
+                               p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, dJ);
+        else
+            hipLaunchKernelGGL((legged_period_kernel<false>), dim3((unsigned)B), dim3(64), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
+                               p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, nullptr);
+        HIP_CHECK(hipGetLastError());
+    }
     if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
     const long long E = (long long)B * p.htraj.N;
@@ -591,6 +617,14 @@ struct LeggedSetup {
     int swing_joint_id = 0;             // Pinocchio id
     double sf_R[9], sf_p[3];            // swing-foot end transform
     raptor_gait_desc gait;
+    // reset-map block
+    bool period = false;
+    int period_contact_joint_id = 0;    // Pinocchio id of the stance foot after reinitialize()
+    double period_endR[9], period_endp[3];
+    std::vector<int> period_id1, period_id2;
+    double period_sign = -1.0;
+    struct PeriodLoop { int nvl, nr, nx, row0, drv[2], var_joint[8]; };
+    std::vector<PeriodLoop> period_loops;   // Digit: index leg * 2 + (0 knee, 1 toe)
 };
 
 static void legged_setup(raptor_problem& pr, const raptor_model* model, const LeggedSetup& S) {
@@ -791,12 +825,87 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     Q.ncust = (int)crow.size();
     Q.off_cust = rt + rq + rcn;
     std::memset(&p->hspheres, 0, sizeof(p->hspheres));
-    p->layout = DevLayout{rt + rq + rcn + Q.ncust, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
-    p->num_blocks = S.cust ? 4 : 3;
+    // reset-map block (*SingleStepPeriodicityConstraints.cpp:12-16): nv + n_dep + Nact + Nact + 7 rows, last
+    Q.nperiod = S.period ? nv + nd + 2 * ni + 7 : 0;
+    Q.off_period = rt + rq + rcn + Q.ncust;
+    if (S.period) {
+        if (S.extra_variables != nv + nd) throw std::invalid_argument("periodicity constraints need v_reset and lambda_reset in z");
+        if (S.period_contact_joint_id < 1 || S.period_contact_joint_id > nv) throw std::runtime_error("Can not find joint");
+        if ((int)S.period_id1.size() != ni || (int)S.period_id2.size() != ni) throw std::invalid_argument("JOINT_MAP must have one pair per independent joint");
+        if (nd > 24) throw unsupported_error("reset-map kernel: at most 24 dependent joints");
+        DevPeriod& P = p->hper;
+        std::memset(&P, 0, sizeof(P));
+        P.nj = nv;
+        P.off = Q.off_period;
+        std::vector<std::vector<int>> kids(nv);
+        std::vector<int> roots;
+        for (int j = 0; j < nv; j++) (m.parent[j] < 0 ? roots : kids[m.parent[j]]).push_back(j);
+        int nl = 0;
+        std::function<void(int, int, int)> walk = [&](int j, int parent_lane, int depth) {
+            if (depth > RAPTOR_LEG_MAX_DEPTH) throw unsupported_error("reset-map kernel: tree deeper than 20");
+            const int lane = nl++;
+            P.lane_joint[lane] = j;
+            P.joint_lane[j] = lane;
+            P.depth[lane] = depth;
+            for (int t = 0; t < depth - 1; t++) P.path[lane][t] = P.path[parent_lane][t];
+            P.path[lane][depth - 1] = lane;
+            for (int c : kids[j]) walk(c, lane, depth + 1);
+            P.end[lane] = nl;
+        };
+        for (int r : roots) walk(r, -1, 1);
+        P.old_foot_lane = P.joint_lane[S.contact_joint_id - 1];
+        P.new_foot_lane = P.joint_lane[S.period_contact_joint_id - 1];
+        for (int k = 0; k < 9; k++) P.endR[k] = S.period_endR[k];
+        for (int k = 0; k < 3; k++) P.endp[k] = S.period_endp[k];
+        for (int k = 0; k < ni; k++) {
+            const int a = S.period_id1[k], c = S.period_id2[k];
+            if (a < 0 || a >= nv || c < 0 || c >= nv) throw std::runtime_error("Can not find joint");
+            P.id1[k] = a;
+            P.id2[k] = c;
+        }
+        P.sign = S.period_sign;
+        for (int j = 0; j < nv; j++) {
+            P.joint_loop[j] = P.joint_var[j] = -1;
+            P.joint_rec[j] = (int)S.loop_rec.size() == nv ? S.loop_rec[j] : -1;
+        }
+        P.nloops = (int)S.period_loops.size();
+        if (P.nloops > RAPTOR_PERIOD_MAX_LOOPS) throw unsupported_error("reset-map kernel: at most 4 closed loops");
+        int off = 0, rows = 0;
+        for (int l = 0; l < P.nloops; l++) {
+            const LeggedSetup::PeriodLoop& pl = S.period_loops[l];
+            P.loop_nvl[l] = pl.nvl; P.loop_nr[l] = pl.nr; P.loop_nx[l] = pl.nx; P.loop_row0[l] = pl.row0;
+            P.loop_col[l][0] = Q.joint_ind[pl.drv[0]];
+            P.loop_col[l][1] = pl.nx > 1 ? Q.joint_ind[pl.drv[1]] : -1;
+            P.loop_off[l] = off;
+            off += pl.nr * pl.nvl + pl.nr + pl.nvl + pl.nr * pl.nx + pl.nvl * pl.nx;
+            for (int k = 0; k < pl.nvl; k++) {
+                P.joint_loop[pl.var_joint[k]] = l;
+                P.joint_var[pl.var_joint[k]] = k;
+            }
+            for (int r = 0; r < pl.nr; r++) {
+                if (pl.row0 + r >= 24) throw unsupported_error("reset-map kernel: closure row out of range");
+                P.row_loop[pl.row0 + r] = l;
+                P.row_local[pl.row0 + r] = r;
+            }
+            rows += pl.nr;
+        }
+        if (rows != nd - 6) throw unsupported_error("reset-map kernel: closure rows must match the dependent joints");
+        P.loop_stride = (off + 1) & ~1;
+        p->d_per.upload(&P, 1);
+        p->has_period = true;
+    }
+    p->layout = DevLayout{rt + rq + rcn + Q.ncust + Q.nperiod, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
+    p->num_blocks = 3;
     p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rcn;
-    p->block_offsets[4] = rt + rq + rcn + Q.ncust;
+    if (S.cust) p->block_offsets[++p->num_blocks] = rt + rq + rcn + Q.ncust;
+    if (S.period) p->block_offsets[++p->num_blocks] = rt + rq + rcn + Q.ncust + Q.nperiod;
     p->g_lb.assign(p->layout.m, 0.0);
     p->g_ub.assign(p->layout.m, 0.0);
+    if (S.period) {  // *SingleStepPeriodicityConstraints.cpp:217-226: equalities, then the seven contact rows
+        const int o5 = Q.off_period + nv + nd + 2 * ni;
+        p->g_ub[o5] = 1e19;
+        for (int k = 1; k < 7; k++) p->g_lb[o5 + k] = -1e19;
+    }
     for (int r = 0; r < Q.ncust; r++) {
         p->g_lb[Q.off_cust + r] = clb[r];
         p->g_ub[Q.off_cust + r] = cub[r];
@@ -886,6 +995,16 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
         for (int k = 0; k < 9; k++) S.sf_R[k] = (k % 4 == 0) ? 1.0 : 0.0;
         for (int k = 0; k < 3; k++) S.sf_p[k] = d->gait.swingfoot_endT_p[k];
         S.gait = d->gait;
+    }
+    if (d->period.enabled) {  // TalosSingleStepOptimizer.cpp:101-106
+        if (!d->period.joint_id1 || !d->period.joint_id2) throw std::invalid_argument("null argument");
+        S.period = true;
+        S.period_contact_joint_id = d->period.swing_contact_joint_id;
+        for (int k = 0; k < 9; k++) S.period_endR[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 3; k++) S.period_endp[k] = d->period.swing_foot_endT_p[k];
+        S.period_id1.assign(d->period.joint_id1, d->period.joint_id1 + d->num_independent);
+        S.period_id2.assign(d->period.joint_id2, d->period.joint_id2 + d->num_independent);
+        S.period_sign = d->period.mirror_sign;
     }
     legged_setup(*p, model, S);
     *out = p.release();
@@ -985,6 +1104,11 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
                 for (int k = 0; k < 3; k++) { cl.endA[k] = lp.rod[k]; cl.endB[k] = an[k]; }
             }
             for (int x = 0; x < ref.ndrv; x++) L.drv_traj[x] = ind_of[ids[ref.drv[x]]];
+            // rows of the loop's closures in the compiled reference order: right toe-A, right toe-B, left toe-A, left toe-B,
+            // right knee, left knee (DigitDynamicsConstraints.cpp:579-596)
+            L.row0 = (type == 1) ? (leg == 1 ? 0 : 6) : (leg == 1 ? 12 : 15);
+            for (int r = 0; r < ref.ndep; r++) L.var_joint[r] = ids[ref.depj[r]];
+            for (int x = 0; x < ref.ndrv; x++) L.var_joint[ref.ndep + x] = ids[ref.drv[x]];
             for (int r = 0; r < ref.ndep; r++) {
                 const int j = ids[ref.depj[r]];
                 S.loop_rec[j] = L.rec0 + r;
@@ -1010,6 +1134,27 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
         S.swing_joint_id = d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1;
         digit_stance_foot_endT(1 - sleg, S.sf_R, S.sf_p);  // DigitCustomizedConstraints.cpp:16-24
         S.gait = d->gait;
+    }
+    if (d->period.enabled) {  // DigitSingleStepOptimizer.cpp:102-106, JOINT_MAP of DigitSingleStepPeriodicityConstraints.h:19-32
+        S.period = true;
+        S.period_contact_joint_id = d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1;
+        digit_stance_foot_endT(1 - sleg, S.period_endR, S.period_endp);  // DigitDynamicsConstraints.cpp:81-95 after the swap
+        for (int leg = 0; leg < 2; leg++)
+            for (int k = 0; k < 6; k++) {
+                S.period_id1.push_back(d->leg_ids[leg][DIGIT_LEG_INDEPENDENT[k]]);
+                S.period_id2.push_back(d->leg_ids[1 - leg][DIGIT_LEG_INDEPENDENT[k]]);
+            }
+        S.period_sign = 1.0;
+        for (int leg = 0; leg < 2; leg++)
+            for (int type = 0; type < 2; type++) {
+                const DevLoop& L = D->loop[leg][type];
+                LeggedSetup::PeriodLoop pl;
+                pl.nvl = L.ny + L.nx; pl.nr = L.ny; pl.nx = L.nx; pl.row0 = L.row0;
+                pl.drv[0] = L.var_joint[L.ny];
+                pl.drv[1] = L.nx > 1 ? L.var_joint[L.ny + 1] : -1;
+                for (int k = 0; k < 8; k++) pl.var_joint[k] = k < pl.nvl ? L.var_joint[k] : -1;
+                S.period_loops.push_back(pl);
+            }
     }
     std::unique_ptr<raptor_problem> p(new raptor_problem());
     legged_setup(*p, model, S);

@@ -476,6 +476,42 @@ def test_customized_block(oracle, hip, robot, stance):
     check(Gh2, Gh, 1e-12)
 
 
+@pytest.mark.parametrize("robot,stance,customized", [("talos", "L", True), ("g1", "R", False), ("digit", "L", True),
+                                                     ("digit", "R", False)])
+def test_reset_map_block(oracle, hip, robot, stance, customized):
+    """Last block: *SingleStepPeriodicityConstraints (nv + n_dep + 2 Nact + 7 rows): H (v+ - v-) - J^T lambda, J v+,
+    position / velocity reset and the contact cone on lambda, with J taken after the stance swap; the whole problem then
+    has the reference's row count (Digit, N = 14, all blocks: 1005)."""
+    N = 6
+    keep = []
+    if robot == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance, customized=customized, periodic=True)
+        ph, _, _ = H.digit_problem(hip, keep, N=N, stance=stance, customized=customized, periodic=True)
+        rows = 36 + 24 + 12 + 12 + 7
+    else:
+        po, m, cfg = H.legged_problem(oracle, robot, keep, N=N, stance=stance, customized=customized, periodic=True)
+        ph, _, _ = H.legged_problem(hip, robot, keep, N=N, stance=stance, customized=customized, periodic=True)
+        rows = 18 + 6 + 12 + 12 + 7
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    assert po.block_offsets[-1] - po.block_offsets[-2] == rows
+    lo, uo = po.bounds()
+    lh, uh = ph.bounds()
+    assert np.array_equal(lo, lh) and np.array_equal(uo, uh)
+    Z = 0.1 * np.random.default_rng(20250523 + 9).uniform(-1, 1, (5, po.n))
+    Z[:, -24:] *= 30.0  # impulses of a realistic size next to the 0.1-sized velocities
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh[:, -rows:], Go[:, -rows:])
+    check(Jh[:, -rows:], Jo[:, -rows:])
+    check(Gh, Go)
+    check(Jh, Jo)
+    Gh2, _ = ph.eval_host(Z, A.EVAL_G)
+    check(Gh2, Gh, 1e-12)
+    if robot == "digit" and customized:
+        p14, _, _ = H.digit_problem(hip, keep, N=14, customized=True, periodic=True)
+        assert p14.m == 1005  # SURVEY 8a: 168 + 504 + 98 + 144 + 91
+
+
 def test_legged_ragged_and_degenerate_sizes(oracle, hip):
     """Odd batch x odd sample counts (half-filled wavefronts), N = 1, an empty batch, and error codes."""
     keep = []
