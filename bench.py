@@ -60,10 +60,10 @@ class Legged:
     """BASELINE configs[2] (Talos) / configs[4] (G1, one GPU's shard of the 8192-problem sweep)."""
     samples = 14
     batch = 1024
-    bytes_per_se = None                   # 8 (m / N) (n + 1): every row written once, g and pg_pz (SURVEY.md 8d)
+    bytes_per_se = None                   # 8 (rows / N) (n + 1): every row the expand kernel writes, once, g and pg_pz (SURVEY.md 8d)
     flops_per_se = 230000                 # SURVEY.md 8d total for Talos / G1 as the reference does it
     dominant = 1
-    kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows)",
+    kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows) + legged_period_kernel (reset-map rows)",
                "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
     pmc_key = "legged_expand_kernel"
     z_scale = 0.1  # TalosSingleStep.cpp:61
@@ -72,12 +72,13 @@ class Legged:
         self.name = which
         self.workload = (f"{'Talos' if which == 'talos' else 'Unitree-G1'} single-step gait, nv=18 (6 floating + 12), Bezier degree 6, "
                          f"14 Chebyshev samples x {self.batch} random z in 0.1*U(-1,1)^108 per GPU, eval_g+eval_jac_g "
-                         "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows), no solver")
+                         "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows + reset map: "
+                         "all 583 rows of the reference's single-step problem), no solver")
 
     def build(self, api, keep):
         import helpers as H
 
-        return H.legged_problem(api, self.name, keep, N=self.samples, customized=True)[0]
+        return H.legged_problem(api, self.name, keep, N=self.samples, customized=True, periodic=True)[0]
 
 
 class Digit:
@@ -85,22 +86,23 @@ class Digit:
     name = "digit"
     samples = 14
     batch = 4096
-    bytes_per_se = None                   # 8 (m / N) (n + 1) for the rows built (torque, joint limits, contact, customized)
+    bytes_per_se = None                   # 8 (rows / N) (n + 1) over the expand kernel's rows (torque, joint limits, contact, customized)
     flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
     dominant = 1
-    kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows)",
+    kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
+               "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
                "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
     pmc_key = "legged_expand_kernel"
     z_scale = 0.1  # DigitSingleStep.cpp:75
     workload = ("Digit-v3 single-step gait, nv=36 (6 floating + 12 actuated + 18 closed-loop), Bezier degree 5, "
                 "14 Chebyshev samples x 4096 random z in 0.1*U(-1,1)^132 per GPU, eval_g+eval_jac_g "
-                "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows: "
-                "914 of the reference's 1005 rows, the periodicity block is not built), no solver")
+                "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows + reset map: "
+                "all 1005 rows of the reference's single-step problem), no solver")
 
     def build(self, api, keep):
         import helpers as H
 
-        return H.digit_problem(api, keep, N=self.samples, customized=True)[0]
+        return H.digit_problem(api, keep, N=self.samples, customized=True, periodic=True)[0]
 
 
 WORKLOADS = {"kinova": Kinova, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1"), "digit": Digit}
@@ -181,7 +183,10 @@ def main() -> None:
         dom_ms = kms[W.dominant]
         dom_s = dom_ms * 1e-3
         tot_s = (k0_ms + k1_ms) * 1e-3
-        bytes_per_se = W.bytes_per_se or 8.0 * prob.m / W.samples * (prob.n + 1)
+        # legged workloads: the dominant (expand) kernel writes every block but the reset map, which legged_period_kernel
+        # writes once per z inside the first kernel group
+        exp_rows = prob.m - (prob.block_offsets[-1] - prob.block_offsets[-2] if getattr(W, "name", "") != "kinova" else 0)
+        bytes_per_se = W.bytes_per_se or 8.0 * exp_rows / W.samples * (prob.n + 1)
         alg_bytes = sample_evals * bytes_per_se
         ms_per_step = 1e3 * elapsed / args.steps
         out = {

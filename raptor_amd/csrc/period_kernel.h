@@ -20,22 +20,24 @@
 #include "digit_kernel.h"
 #include "legged_kernel.h"
 
+#define PL_WAVES 2   // wavefronts per decision vector: each takes every other manifold direction
+#define PL_BLOCK (64 * PL_WAVES)
 // LDS map of legged_period_kernel (doubles)
 #define PL_LOC 0                                   // [nv][16] local joint transform: X (9), t (3), axis (3), prismatic flag
 #define PL_S (PL_LOC + RAPTOR_MAX_NV * 16)         // [nv][6] world-frame joint axes, by lane
-#define PL_DV (PL_S + RAPTOR_MAX_NV * 6)           // by lane: v+ - v-, v+, v-, u (direction), Vq (direction)
+#define PL_DV (PL_S + RAPTOR_MAX_NV * 6)           // by lane: v+ - v-, v+, v-
 #define PL_VP (PL_DV + RAPTOR_MAX_NV)
 #define PL_VM (PL_VP + RAPTOR_MAX_NV)
-#define PL_U (PL_VM + RAPTOR_MAX_NV)
-#define PL_VQ (PL_U + RAPTOR_MAX_NV)
-#define PL_H (PL_VQ + RAPTOR_MAX_NV)               // [nv][nv] crba(q-) incl. armature, by model joint
+#define PL_U (PL_VM + RAPTOR_MAX_NV)                // [PL_WAVES][2][nv] per wavefront: u, Vq of the direction it works on
+#define PL_H (PL_U + PL_WAVES * 2 * RAPTOR_MAX_NV)  // [nv][nv] crba(q-) incl. armature, by model joint
 #define PL_JA (PL_H + RAPTOR_MAX_NV * RAPTOR_MAX_NV)  // [nd][nv] constraint Jacobian after the swap
 #define PL_D1 (PL_JA + 24 * RAPTOR_MAX_NV)         // [nv][ni] coefficient of B_k(T) in the g1 rows
 #define PL_D2 (PL_D1 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nv][ni] coefficient of dB_k(T)
 #define PL_G2 (PL_D2 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nd][ni] D_t (J v+)
 #define PL_W (PL_G2 + 24 * RAPTOR_LEG_MAX_IND)     // [4][16] B, dB of the first sample, B, dB of the last
 #define PL_C5 (PL_W + 64)                          // [7][6] d g5 / d lambda.tail(6)
-#define PL_TOTAL (PL_C5 + 42)
+#define PL_E (PL_C5 + 42)                          // [3][3] E = d rpy / d omega at the contact frame; then [3][3] A_ij = m . T_ij,
+#define PL_TOTAL (PL_E + 27)                       // [3][3] B_j = sum_i T_ij omega+_i   (T_ij = d_rpy_rates(R_c, e_i, e_j))
 
 // directional derivative of rpy_rates(R, w) with respect to R along dR = [ww]x R (w fixed): the second-order part of
 // ForwardKinematicsSolver::getRPYHessian (ForwardKinematics.cpp:445-498)
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* _
 }
 
 template <bool DERIV>
-__global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+__global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
                                                            const DevLegged* __restrict__ Q, const DevPeriod* __restrict__ P,
                                                            const double* __restrict__ basis, const DevLayout L,
                                                            const double* __restrict__ Z, const double* __restrict__ core,
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
                                                            const double* __restrict__ ploops, double* __restrict__ G,
                                                            double* __restrict__ JAC) {
     extern __shared__ double lds[];
-    const int g = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int g = tid & 63;
+    const int wv = tid >> 6;       // every wavefront repeats the cheap phases 0-B in registers; wavefront 0 owns the stores
+    const bool lead = wv == 0;
     const long long b = blockIdx.x;
     const int nj = P->nj, ni = Q->ni, nd = Q->nd, nv = Q->nv, K = Q->K, n = L.n, N = T->N;
     const int ncl = nd - 6;  // closure rows
@@ -185,13 +190,13 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
               mynx = (myloop >= 0) ? P->loop_nx[myloop] : 0;
 
     // ---- phase 0: this joint's local transform at q-, the reset velocities; clear the sparse pieces ----
-    for (int k = g; k < RAPTOR_MAX_NV * RAPTOR_MAX_NV + 24 * RAPTOR_MAX_NV; k += 64) lds[PL_H + k] = 0.0;  // H and JA are adjacent
-    for (int k = g; k < 24 * RAPTOR_LEG_MAX_IND; k += 64) lds[PL_G2 + k] = 0.0;
+    for (int k = tid; k < RAPTOR_MAX_NV * RAPTOR_MAX_NV + 24 * RAPTOR_MAX_NV; k += PL_BLOCK) lds[PL_H + k] = 0.0;  // H and JA are adjacent
+    for (int k = tid; k < 24 * RAPTOR_LEG_MAX_IND; k += PL_BLOCK) lds[PL_G2 + k] = 0.0;
     const double qm = on ? recN[Q->c_q + jnt] : 0.0;
     const double vm = on ? recN[Q->c_v + jnt] : 0.0;
     const double vpl = on ? z[cv + jnt] : 0.0;
     const double dvj = vpl - vm;
-    if (on) {
+    if (on && lead) {
         double sq, cq;
         sincos(qm, &sq, &cq);
         M3 Pm, X;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         lds[PL_VP + g] = vpl;
         lds[PL_VM + g] = vm;
     }
-    wave_sync();
+    __syncthreads();
 
     // ---- phase A: world-frame pose and joint axis (walk from the world down to this joint) ----
     M3 Rw;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         Rw = R;
         ow = o;
     }
-    if (on) lds_put(lds + PL_S + g * 6, s);
+    if (on && lead) lds_put(lds + PL_S + g * 6, s);
     InertiaO I;
     {
         Inertia Ic;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         I.xz = keep * Ic.xz - m * c.x * c.z;
         I.yz = keep * Ic.yz - m * c.y * c.z;
     }
-    wave_sync();
+    __syncthreads();
 
     // ---- phase B: values.  a = sum s_j (v+ - v-)_j, V+ = sum s_j v+_j along the path; contact point after the swap ----
     SV aD = sv_zero(), Vp = sv_zero();
@@ -271,10 +276,37 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
     }
     const V3 lt = v3(z[cl + nd - 6], z[cl + nd - 5], z[cl + nd - 4]);
     const V3 lr = v3(z[cl + nd - 3], z[cl + nd - 2], z[cl + nd - 1]);
+    const V3 wp = v3(__shfl(Vp.a.x, nf, 64), __shfl(Vp.a.y, nf, 64), __shfl(Vp.a.z, nf, 64));  // omega+ of the new stance foot
+    // E = d rpy / d omega at the contact frame, and the bilinear form T_ij = d_rpy_rates(R_c, e_i, e_j) contracted with the
+    // two fixed vectors it meets (m = lambda's moment part, omega+): nine lanes evaluate one (i, j) pair each, once
+    if (lead && g < 9) {
+        const int i = g / 3, j = g - 3 * i;
+        const V3 ei = v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0);
+        const V3 ej = v3(j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0);
+        const V3 Tij = d_rpy_rates(Rc, ei, ej);
+        lds[PL_E + 9 + g] = dot(lr, Tij);                  // A[i][j]
+        const double wi = (i == 0) ? wp.x : ((i == 1) ? wp.y : wp.z);
+        lds[PL_E + 18 + g] = 0.0;
+        // B[:, j] += T_ij * omega+_i : three lanes (i = 0..2) per j, summed below through LDS
+        lds[PL_LOC + g * 3] = Tij.x * wi; lds[PL_LOC + g * 3 + 1] = Tij.y * wi; lds[PL_LOC + g * 3 + 2] = Tij.z * wi;
+        if (j == 0) {  // E[:, i] = rpy_rates(R_c, e_i)
+            const V3 Ei = rpy_rates(Rc, ei);
+            lds[PL_E + i] = Ei.x; lds[PL_E + 3 + i] = Ei.y; lds[PL_E + 6 + i] = Ei.z;
+        }
+    }
+    __syncthreads();
+    if (lead && g < 9) {  // B[r][j] = sum_i T_ij[r] omega+_i
+        const int r = g / 3, j = g - 3 * r;
+        lds[PL_E + 18 + g] = lds[PL_LOC + (0 * 3 + j) * 3 + r] + lds[PL_LOC + (1 * 3 + j) * 3 + r] + lds[PL_LOC + (2 * 3 + j) * 3 + r];
+    }
+    __syncthreads();
+    const double* Em = lds + PL_E;
+#define E_MUL(q_) v3(Em[0] * (q_).x + Em[1] * (q_).y + Em[2] * (q_).z, Em[3] * (q_).x + Em[4] * (q_).y + Em[5] * (q_).z, Em[6] * (q_).x + Em[7] * (q_).y + Em[8] * (q_).z)
     const SV Ia = applyO(I, aD);
     SV f = Ia;
     if (g == nf) {  // - J_foot^T lambda.tail(6) is a wrench at the contact point: [p_c x f + E^T m ; f]
-        const V3 Etl = v3(dot(lr, rpy_rates(Rc, v3(1, 0, 0))), dot(lr, rpy_rates(Rc, v3(0, 1, 0))), dot(lr, rpy_rates(Rc, v3(0, 0, 1))));
+        const V3 Etl = v3(Em[0] * lr.x + Em[3] * lr.y + Em[6] * lr.z, Em[1] * lr.x + Em[4] * lr.y + Em[7] * lr.z,
+                          Em[2] * lr.x + Em[5] * lr.y + Em[8] * lr.z);
         f = f - SV{cross(pc, lt) + Etl, lt};
     }
     SV F = f;
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
     CUT(IC.m) CUT(IC.hv.x) CUT(IC.hv.y) CUT(IC.hv.z)
     CUT(IC.xx) CUT(IC.xy) CUT(IC.xz) CUT(IC.yy) CUT(IC.yz) CUT(IC.zz)
 
-    if (on) {
+    if (on && lead) {
         // (1) H (v+ - v-) - J^T lambda   (:88-98)
         double val = dot(s, F) + arm * dvj;
         if (myloop >= 0) val -= mypl[mynr * mynvl + mynr + myvar];
@@ -311,7 +343,7 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         // stance-foot rows of J after the swap (TalosDynamicsConstraints.cpp:264-279): translation and RPY Jacobian columns
         if (g <= nf && nf < gend) {
             const V3 Jt = s.l + cross(s.a, pc);
-            const V3 Jr = rpy_rates(Rc, s.a);
+            const V3 Jr = E_MUL(s.a);
             double* ja = lds + PL_JA + ncl * nv + jnt;
             ja[0] = Jt.x; ja[nv] = Jt.y; ja[2 * nv] = Jt.z;
             ja[3 * nv] = Jr.x; ja[4 * nv] = Jr.y; ja[5 * nv] = Jr.z;
@@ -322,11 +354,11 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
             for (int r = 0; r < mynr; r++) lds[PL_JA + (row0 + r) * nv + jnt] = mypl[r * mynvl + myvar];
         }
     }
-    if (G != nullptr) {
+    if (G != nullptr && lead) {
         // (2) J v+   (:119-120)
         if (g == nf) {
             const V3 lin = Vp.l + cross(Vp.a, pc);
-            const V3 rot = rpy_rates(Rc, Vp.a);
+            const V3 rot = E_MUL(Vp.a);
             double* o = G + rowbase + nv + ncl;
             o[0] = lin.x; o[1] = lin.y; o[2] = lin.z; o[3] = rot.x; o[4] = rot.y; o[5] = rot.z;
         }
@@ -356,8 +388,10 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
     if (!DERIV) return;
 
     // ---- phase C: the twelve manifold directions ----
+    double* myU = lds + PL_U + wv * 2 * RAPTOR_MAX_NV;
+    double* myVQ = myU + RAPTOR_MAX_NV;
 #pragma unroll 1
-    for (int t = 0; t < ni; t++) {
+    for (int t = wv; t < ni; t += PL_WAVES) {
         {   // this joint's rate along the direction, and d v-/d q_t of a closed-loop joint (Y2 contracted with the drivers' rates)
             double u = 0.0, vq = 0.0;
             if (on) {
@@ -374,8 +408,8 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
                     if (t == c0) vq = y[3] * va + y[4] * vb;
                     else if (t == c1) vq = y[4] * va + y[5] * vb;
                 }
-                lds[PL_U + g] = u;
-                lds[PL_VQ + g] = vq;
+                myU[g] = u;
+                myVQ[g] = vq;
             }
         }
         wave_sync();
@@ -384,12 +418,12 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         for (int d = 0; d < depth; d++) {
             const int j = P->path[gj][d];
             const SV sj = lds_sv(lds + PL_S + j * 6);
-            w = w + sj * lds[PL_U + j];
+            w = w + sj * myU[j];
             const SV c = crm(w, sj);
             CD = CD + c * lds[PL_DV + j];
             Cp = Cp + c * lds[PL_VP + j];
             Cm = Cm + c * lds[PL_VM + j];
-            Sq = Sq + sj * lds[PL_VQ + j];
+            Sq = Sq + sj * myVQ[j];
         }
         // the old stance foot stays planted along the direction: sum_base s_b Vq_b = -(Cm + Sq) at its lane
         SV rof = Cm + Sq;
@@ -398,9 +432,10 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         const SV da = CD - Sq + rof;
         SV df = crf(w, Ia) - applyO(I, crm(w, aD)) + applyO(I, da);
         const V3 dpc = w.l + cross(w.a, pc);  // meaningful on the new stance foot's lane
-        if (g == nf) {
-            const V3 dEtl = v3(dot(lr, d_rpy_rates(Rc, v3(1, 0, 0), w.a)), dot(lr, d_rpy_rates(Rc, v3(0, 1, 0), w.a)),
-                               dot(lr, d_rpy_rates(Rc, v3(0, 0, 1), w.a)));
+        if (g == nf) {  // D_t (E^T m)_i = sum_j (m . T_ij) w_j
+            const double* Am = lds + PL_E + 9;
+            const V3 dEtl = v3(Am[0] * w.a.x + Am[1] * w.a.y + Am[2] * w.a.z, Am[3] * w.a.x + Am[4] * w.a.y + Am[5] * w.a.z,
+                               Am[6] * w.a.x + Am[7] * w.a.y + Am[8] * w.a.z);
             df = df - SV{cross(dpc, lt) + dEtl, v3(0, 0, 0)};
         }
         SV dF = on ? df : sv_zero();
@@ -414,18 +449,20 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         CUT(dF.a.x) CUT(dF.a.y) CUT(dF.a.z) CUT(dF.l.x) CUT(dF.l.y) CUT(dF.l.z)
         CUT(FP.a.x) CUT(FP.a.y) CUT(FP.a.z) CUT(FP.l.x) CUT(FP.l.y) CUT(FP.l.z)
         if (on) {
-            double d1 = dot(crm(w, s), F) + dot(s, dF) - arm * lds[PL_VQ + g];
+            double d1 = dot(crm(w, s), F) + dot(s, dF) - arm * myVQ[g];
             if (myloop >= 0) {
                 const double* dj = mypl + mynr * mynvl + mynr + mynvl + mynr * mynx + myvar * mynx;
                 if (t == P->loop_col[myloop][0]) d1 -= dj[0];
                 else if (mynx > 1 && t == P->loop_col[myloop][1]) d1 -= dj[1];
             }
             lds[PL_D1 + jnt * ni + t] = d1;
-            lds[PL_D2 + jnt * ni + t] = -(dot(s, FP) + arm * lds[PL_U + g]);
+            lds[PL_D2 + jnt * ni + t] = -(dot(s, FP) + arm * myU[g]);
         }
         if (g == nf) {  // D_t (J_foot v+)
             const V3 lin = Cp.l + cross(Cp.a, pc) + cross(Vp.a, dpc);
-            const V3 rot = d_rpy_rates(Rc, Vp.a, w.a) + rpy_rates(Rc, Cp.a);
+            const double* Bm = lds + PL_E + 18;
+            const V3 rot = v3(Bm[0] * w.a.x + Bm[1] * w.a.y + Bm[2] * w.a.z, Bm[3] * w.a.x + Bm[4] * w.a.y + Bm[5] * w.a.z,
+                              Bm[6] * w.a.x + Bm[7] * w.a.y + Bm[8] * w.a.z) + E_MUL(Cp.a);
             double* o = lds + PL_G2 + ncl * ni + t;
             o[0] = lin.x; o[ni] = lin.y; o[2 * ni] = lin.z; o[3 * ni] = rot.x; o[4 * ni] = rot.y; o[5 * ni] = rot.z;
         }
@@ -442,13 +479,13 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
 #undef CUT
 
     // ---- phase D: Bernstein weights of the first and last sample, d g5, then the dense rows ----
-    if (g < K) {
+    if (lead && g < K) {
         lds[PL_W + g] = basis[g];                                 // B_k(t_0)
         lds[PL_W + 16 + g] = basis[K + g];                        // dB_k(t_0)
         lds[PL_W + 32 + g] = basis[(size_t)((N - 1) * 3) * K + g];      // B_k(t_N-1)
         lds[PL_W + 48 + g] = basis[(size_t)((N - 1) * 3 + 1) * K + g];  // dB_k(t_N-1)
     }
-    if (g < 42) {  // d g5 / d lambda.tail(6)   (:181-204)
+    if (lead && g < 42) {  // d g5 / d lambda.tail(6)   (:181-204)
         const int r = g / 6, c = g - r * 6;
         const double fz = lt.z, mu = Q->mu, gam = Q->gamma;
         double val = 0.0;
@@ -463,41 +500,75 @@ __global__ __launch_bounds__(64) void legged_period_kernel(const DevModel* __res
         }
         lds[PL_C5 + g] = val;
     }
-    wave_sync();
+    __syncthreads();
+    // every thread owns a pair of adjacent columns (classified once) and walks down the rows: 16-byte stores, a row's
+    // pairs contiguous across the lanes, no per-element index arithmetic
     const int ndyn = ni * K;
-    const int mp = nv + nd + 2 * ni + 7;
     double* out = JAC + rowbase * n;
-    const int total = mp * n;
-    int r = g / n, c = g - r * n;
-    const int dr = 64 / n, dc = 64 - dr * n;
-    for (int idx = g; idx < total; idx += 64) {
-        double val = 0.0;
-        const bool dyn = c < ndyn;
-        const int t = dyn ? c / K : 0, k = dyn ? c - t * K : 0;
-        if (r < nv) {  // pg1_pz (:114-116)
-            if (dyn) val = lds[PL_D1 + r * ni + t] * lds[PL_W + 32 + k] + lds[PL_D2 + r * ni + t] * lds[PL_W + 48 + k];
-            else if (c >= cl) val = -lds[PL_JA + (c - cl) * nv + r];
-            else if (c >= cv) val = lds[PL_H + r * nv + (c - cv)];
-        } else if (r < nv + nd) {  // pg2_pz (:126-127)
-            const int d = r - nv;
-            if (dyn) val = lds[PL_G2 + d * ni + t] * lds[PL_W + 32 + k];
-            else if (c >= cv && c < cl) val = lds[PL_JA + d * nv + (c - cv)];
-        } else if (r < nv + nd + ni) {  // pg3_pz (:137)
-            const int i = r - nv - nd;
-            if (dyn) val = ((t == Q->joint_ind[P->id1[i]]) ? lds[PL_W + k] : 0.0) + ((t == Q->joint_ind[P->id2[i]]) ? P->sign * lds[PL_W + 32 + k] : 0.0);
-        } else if (r < nv + nd + 2 * ni) {  // pg4_pz (:148)
-            const int i = r - nv - nd - ni;
-            if (dyn) val = (t == Q->joint_ind[P->id1[i]]) ? lds[PL_W + 16 + k] : 0.0;
-            else if (c >= cv && c < cl) val = (c - cv == P->id2[i]) ? P->sign : 0.0;
-        } else {  // pg5_pz
-            const int i = r - nv - nd - 2 * ni;
-            if (c >= n - 6) val = lds[PL_C5 + i * 6 + (c - (n - 6))];
+    const bool pairok = ((n & 1) == 0) && ((reinterpret_cast<size_t>(JAC) & 15) == 0);
+    const int wdt = pairok ? 2 : 1;
+    const int ncp = (n + wdt - 1) / wdt;
+    const double* D1s = lds + PL_D1;
+    const double* D2s = lds + PL_D2;
+    const double* G2s = lds + PL_G2;
+    const double* Hs = lds + PL_H;
+    const double* JAs = lds + PL_JA;
+    const double sgn = P->sign;
+    for (int cp = tid; cp < ncp; cp += PL_BLOCK) {
+        const int c0 = cp * wdt;
+        int kind[2], t[2], a[2];
+        double wn0[2], wn1[2], w00[2], w01[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c = c0 + ((h < wdt) ? h : 0);
+            kind[h] = (c < ndyn) ? 0 : ((c < cl) ? 1 : 2);
+            t[h] = (c < ndyn) ? c / K : 0;
+            const int k = (c < ndyn) ? c - t[h] * K : 0;
+            a[h] = (c < ndyn) ? 0 : ((c < cl) ? c - cv : c - cl);
+            w00[h] = lds[PL_W + k]; w01[h] = lds[PL_W + 16 + k]; wn0[h] = lds[PL_W + 32 + k]; wn1[h] = lds[PL_W + 48 + k];
         }
-        out[idx] = val;
-        r += dr;
-        c += dc;
-        if (c >= n) { c -= n; r++; }
+        double* o = out + c0;
+#define PUT(v0, v1) { if (pairok) store2_stream(o, v0, v1); else o[0] = v0; o += n; }
+        for (int r = 0; r < nv; r++) {  // pg1_pz (:114-116)
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                v[h] = (kind[h] == 0) ? D1s[r * ni + t[h]] * wn0[h] + D2s[r * ni + t[h]] * wn1[h]
+                                      : ((kind[h] == 1) ? Hs[r * nv + a[h]] : -JAs[a[h] * nv + r]);
+            PUT(v[0], v[1])
+        }
+        for (int d = 0; d < nd; d++) {  // pg2_pz (:126-127)
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                v[h] = (kind[h] == 0) ? G2s[d * ni + t[h]] * wn0[h] : ((kind[h] == 1) ? JAs[d * nv + a[h]] : 0.0);
+            PUT(v[0], v[1])
+        }
+        for (int i = 0; i < ni; i++) {  // pg3_pz (:137)
+            const int t1 = Q->joint_ind[P->id1[i]], t2 = Q->joint_ind[P->id2[i]];
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w00[h] : 0.0) + ((t[h] == t2) ? sgn * wn0[h] : 0.0) : 0.0;
+            PUT(v[0], v[1])
+        }
+        for (int i = 0; i < ni; i++) {  // pg4_pz (:148)
+            const int t1 = Q->joint_ind[P->id1[i]], j2 = P->id2[i];
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w01[h] : 0.0) : ((kind[h] == 1 && a[h] == j2) ? sgn : 0.0);
+            PUT(v[0], v[1])
+        }
+        for (int i = 0; i < 7; i++) {  // pg5_pz (:181-204)
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) v[h] = (kind[h] == 2 && a[h] >= nd - 6) ? lds[PL_C5 + i * 6 + a[h] - (nd - 6)] : 0.0;
+            PUT(v[0], v[1])
+        }
+#undef PUT
     }
+#undef E_MUL
 }
 
 #endif

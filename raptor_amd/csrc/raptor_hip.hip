@@ -364,10 +364,10 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         }
         const size_t plds = (size_t)PL_TOTAL * sizeof(double);
         if (jac)
-            hipLaunchKernelGGL((legged_period_kernel<true>), dim3((unsigned)B), dim3(64), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
+            hipLaunchKernelGGL((legged_period_kernel<true>), dim3((unsigned)B), dim3(PL_BLOCK), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
                                p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, dJ);
         else
-            hipLaunchKernelGGL((legged_period_kernel<false>), dim3((unsigned)B), dim3(64), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
+            hipLaunchKernelGGL((legged_period_kernel<false>), dim3((unsigned)B), dim3(PL_BLOCK), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
                                p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, nullptr);
         HIP_CHECK(hipGetLastError());
     }
