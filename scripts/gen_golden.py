@@ -46,6 +46,16 @@ def main():
     r = p.constrained_id_host(Z, 2, 36, 12)
     np.savez(os.path.join(OUT, "digit_N2.npz"), Z=Z, G=G, J=J, q=r["q"], tau=r["tau"], lam=r["lam"],
              block_offsets=np.array(p.block_offsets))
+    # the complete single-step problems (customized + reset-map blocks on)
+    for which in ("talos", "digit"):
+        if which == "digit":
+            p, m, cfg = H.digit_problem(oracle, keep, N=2, customized=True, periodic=True)
+        else:
+            p, m, cfg = H.legged_problem(oracle, which, keep, N=2, customized=True, periodic=True)
+        Z = 0.1 * np.random.default_rng(20250523 + 100 + len(which)).uniform(-1, 1, (1, p.n))
+        Z[:, -6:] *= 30.0
+        G, J = p.eval_host(Z)
+        np.savez_compressed(os.path.join(OUT, f"{which}_full_N2.npz"), Z=Z, G=G, J=J, block_offsets=np.array(p.block_offsets))
     json.dump([dict(p11=c[0], p12=c[1], p21=c[2], p22=c[3], r11=c[4], r12=c[5], r21=c[6], r22=c[7], distance=c[8])
                for c in CAPSULE_KNOWN], open(os.path.join(OUT, "capsule_known_answers.json"), "w"), indent=1)
     for f in sorted(os.listdir(OUT)):

@@ -18,10 +18,14 @@ def _problem(api, name, keep, kinova):
         return H.kinova_problem(api, kinova, keep, N=4, boxes=H.reach_boxes())
     if name == "digit_N2":
         return H.digit_problem(api, keep, N=2)[0]
+    if name == "digit_full_N2":
+        return H.digit_problem(api, keep, N=2, customized=True, periodic=True)[0]
+    if name == "talos_full_N2":
+        return H.legged_problem(api, "talos", keep, N=2, customized=True, periodic=True)[0]
     return H.legged_problem(api, name.split("_")[0], keep, N=2)[0]
 
 
-NAMES = ["kinova_N4", "talos_N2", "g1_N2", "digit_N2"]
+NAMES = ["kinova_N4", "talos_N2", "g1_N2", "digit_N2", "talos_full_N2", "digit_full_N2"]
 
 
 @pytest.mark.parametrize("name", NAMES)

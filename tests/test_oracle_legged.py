@@ -161,3 +161,54 @@ def test_customized_block_layout_and_fd(oracle, robot):
         zm[0, c] -= h
         fd = (p.eval_host(zp, A.EVAL_G)[0][0, off:] - p.eval_host(zm, A.EVAL_G)[0][0, off:]) / (2 * h)
         assert np.abs(fd - J[0, off:, c]).max() < 1e-6
+
+
+@pytest.mark.parametrize("robot", ["talos", "g1", "digit"])
+def test_reset_map_block_layout_bounds_and_fd(oracle, robot):
+    """*SingleStepPeriodicityConstraints: row count and bounds (.cpp:12-16, 217-226) and the reference's own recipe for
+    constraint gradients -- central differences of g against pg_pz over every kind of column (trajectory, v+, lambda)."""
+    from raptor_amd import _capi as A
+
+    keep = []
+    N = 4
+    if robot == "digit":
+        p, m, cfg = H.digit_problem(oracle, keep, N=N, periodic=True)
+    else:
+        p, m, cfg = H.legged_problem(oracle, robot, keep, N=N, periodic=True)
+    nv, nd, ni = m.nv, len(cfg.dependent_ids), 12
+    rows = nv + nd + 2 * ni + 7
+    off = p.block_offsets[-2]
+    assert p.block_offsets[-1] - off == rows == p.m - off
+    lb, ub = p.bounds()
+    o5 = off + nv + nd + 2 * ni
+    assert np.all(lb[off:o5] == 0) and np.all(ub[off:o5] == 0)
+    assert lb[o5] == 0 and ub[o5] == 1e19 and np.all(lb[o5 + 1:o5 + 7] == -1e19) and np.all(ub[o5 + 1:o5 + 7] == 0)
+    rng = np.random.default_rng(8)
+    Z = 0.1 * rng.uniform(-1, 1, (1, p.n))
+    Z[0, -6:] *= 30
+    G, J = p.eval_host(Z)
+    h = 1e-6
+    cols = list(range(0, p.n - nv - nd, 5)) + list(range(p.n - nv - nd, p.n, 7)) + list(range(p.n - 6, p.n))
+    for c in cols:
+        zp, zm = Z.copy(), Z.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        fd = (p.eval_host(zp, A.EVAL_G)[0][0, off:] - p.eval_host(zm, A.EVAL_G)[0][0, off:]) / (2 * h)
+        assert np.abs(fd - J[0, off:, c]).max() < 1e-5 * (1 + np.abs(J[0, off:, c]).max()), c
+    # a consistent impact: with v+ = v- and lambda = 0 the first block vanishes, and J v- = 0 would need the OLD stance
+    Z2 = Z.copy()
+    r = p.constrained_id_host(Z2, N, nv, ni, derivatives=False)
+    Z2[0, p.n - nv - nd:p.n - nd] = r["v"][0, N - 1]
+    Z2[0, p.n - nd:] = 0
+    G2, _ = p.eval_host(Z2, A.EVAL_G)
+    assert np.abs(G2[0, off:off + nv]).max() < 1e-10
+
+
+@pytest.mark.parametrize("robot", ["talos", "digit"])
+def test_independent_formulation_reset_map(oracle, robot):
+    """numpy model of the directional-derivative formulation the HIP kernel uses (scripts/proto_period.py) against the
+    oracle's literal restatement (crba, J tensors, gravity-free RNEA derivatives, dense products)."""
+    import proto_period
+
+    eg, ej = proto_period.run(robot, N=3)
+    assert eg < 1e-11 and ej < 1e-10
