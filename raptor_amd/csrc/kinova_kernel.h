@@ -59,6 +59,79 @@ RD SV applyQ(const double* Q, V3 t, SV x) {
 }
 RD double shfl_down8(double x, int d) { return __shfl_down(x, d, KG); }
 
+// ---- BoxCollisionAvoidance (Constraints/src/BoxCollisionAvoidance.cpp:92-137, 290-373) ----
+// Running arg-min over the boxes.  `key` = sign * |diff|^2 (0 below SQUARE_ROOT_THRESHOLD) orders candidates exactly as the
+// reference's dist = sign * sqrt(|diff|^2) does whenever the keys differ by more than rounding; only near-ties take the two
+// square roots the reference compares, so first-minimum-wins is kept bit for bit while the box loop carries no sqrt.
+struct BoxBest {
+    double key, d2, sign;
+    V3 dl;    // point - closest point, in the box frame
+    int idx;
+};
+RD double box_signed_distance(double d2, double sign) { return (d2 > 1e-12) ? sign * sqrt(d2) : 0.0; }  // SQUARE_ROOT_THRESHOLD
+RD double box_best_distance(const BoxBest& b) { return box_signed_distance(b.d2, b.sign); }
+RD V3 sphere_centre(const double* sl, const DevSpheres* __restrict__ S, int sp, int jid) {
+    const double* ro = sl + KL_RO + S->ro_slot[jid - 1] * 12;
+    M3 R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.m[k] = ro[k];
+    return v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+}
+RD void box_candidate(const DevBox* __restrict__ bx, int ob, V3 point, BoxBest& best) {
+    M3 Rb;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+    const V3 lp = mulT(Rb, point - v3(bx->center[0], bx->center[1], bx->center[2]));
+    const double lpv[3] = {lp.x, lp.y, lp.z};
+    double lc[3], dface[3][2];
+    double isInside = -1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double hs = bx->size[k] / 2.0;
+        dface[k][0] = lpv[k] + hs;
+        dface[k][1] = hs - lpv[k];
+        lc[k] = fmax(-hs, fmin(lpv[k], hs));
+        if (lc[k] != lpv[k]) isInside = 1.0;
+    }
+    if (isInside == -1.0) {  // inside: snap to the nearest face, first minimum wins (:112-131)
+        double md = 1e19;
+        int face = 0, dir = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
+            if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (k == face) lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0;
+    }
+    // |point - closest| is rotation invariant: measure it in the box frame
+    const V3 dl = v3(lpv[0] - lc[0], lpv[1] - lc[1], lpv[2] - lc[2]);
+    const double d2 = dot(dl, dl);
+    const double key = (d2 > 1e-12) ? isInside * d2 : 0.0;
+    const double diff = key - best.key;
+    bool closer = diff < 0.0;
+    if (fabs(diff) <= 1e-14 * fmax(fabs(key), fabs(best.key)))  // near-tie: the reference's own comparison (:305-308, strict)
+        closer = box_signed_distance(d2, isInside) < box_signed_distance(best.d2, best.sign);
+    if (closer) {
+        best.key = key;
+        best.idx = ob;
+        best.d2 = d2;
+        best.sign = isInside;
+        best.dl = dl;
+    }
+}
+// gradient of the arg-min box (:359-372) as a wrench: the clamped-axis mask of the reference drops out (diff has no
+// component along unclamped axes), d dist/dz_c = sign * diff . dp/dz_c / |diff| and diff . (w x (p - o)) = s_c . [p x diff ; diff]
+RD SV box_gradient_wrench(const DevBox* __restrict__ bx, const BoxBest& best, V3 point, double w0) {
+    M3 Rb;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+    const double scale = (best.d2 > 1e-12) ? best.sign * w0 / sqrt(best.d2) : 0.0;
+    const V3 dw = mul(Rb, best.dl) * scale;
+    return SV{cross(point, dw), dw};
+}
+
 template <bool DERIV>
 __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
@@ -234,8 +307,14 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         wave_sync();  // the exchange area is reused for the sphere rows below
 
         // ---- spheres: KinovaCustomizedConstraints.cpp:88-157, BoxCollisionAvoidance.cpp:92-137, 290-373 ----
+        // Whole rounds give one sphere to each of the 8 lanes.  A short last round (17 spheres: one left over) would leave
+        // seven lanes idle through the whole box loop, so its spheres are taken one at a time with the BOXES dealt to the
+        // lanes and an 8-lane arg-min that keeps the reference's first-minimum-wins rule (lowest box index on a tie).
         const int O = S->num_obstacles;
-        for (int sp = g; sp < ns; sp += KG) {
+        const int full = (ns / KG) * KG, rem = ns - full;
+        const bool split_tail = rem > 0 && rem * ((O + KG - 1) / KG + 2) < O;
+        const int lim = split_tail ? full : ns;
+        for (int sp = g; sp < lim; sp += KG) {
             const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
             if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
                 if (G != nullptr) G[row] = 0.0;
@@ -245,71 +324,41 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 continue;
             }
             const int jid = S->joint_id[sp];
-            const double* ro = sl + KL_RO + S->ro_slot[jid - 1] * 12;
-            M3 R;
-#pragma unroll
-            for (int k = 0; k < 9; k++) R.m[k] = ro[k];
-            const V3 point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
-            double minDist = 1e19, bd2 = 0.0, bsign = 1.0;
-            V3 bdl = v3(0, 0, 0);
-            int minIdx = 0;
-            for (int ob = 0; ob < O; ob++) {
-                const DevBox* __restrict__ bx = boxes + ob;
-                M3 Rb;
-#pragma unroll
-                for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
-                const V3 lp = mulT(Rb, point - v3(bx->center[0], bx->center[1], bx->center[2]));
-                const double lpv[3] = {lp.x, lp.y, lp.z};
-                double lc[3], dface[3][2];
-                double isInside = -1.0;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const double hs = bx->size[k] / 2.0;
-                    dface[k][0] = lpv[k] + hs;
-                    dface[k][1] = hs - lpv[k];
-                    lc[k] = fmax(-hs, fmin(lpv[k], hs));
-                    if (lc[k] != lpv[k]) isInside = 1.0;
-                }
-                if (isInside == -1.0) {  // inside: snap to the nearest face, first minimum wins (:112-131)
-                    double md = 1e19;
-                    int face = 0, dir = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        if (dface[k][0] < md) { md = dface[k][0]; face = k; dir = 0; }
-                        if (dface[k][1] < md) { md = dface[k][1]; face = k; dir = 1; }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        if (k == face) lc[k] = (dir == 0) ? -bx->size[k] / 2.0 : bx->size[k] / 2.0;
-                }
-                // |point - closest| is rotation invariant: measure it in the box frame
-                const V3 dl = v3(lpv[0] - lc[0], lpv[1] - lc[1], lpv[2] - lc[2]);
-                const double d2 = dot(dl, dl);
-                const double dist = (d2 > 1e-12) ? isInside * sqrt(d2) : 0.0;  // SQUARE_ROOT_THRESHOLD
-                if (dist < minDist) {  // strict: first minimum wins (:305-308)
-                    minDist = dist;
-                    minIdx = ob;
-                    bd2 = d2;
-                    bsign = isInside;
-                    bdl = dl;
-                }
-            }
-            if (G != nullptr) G[row] = minDist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
+            const V3 point = sphere_centre(sl, S, sp, jid);
+            BoxBest best;
+            best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
+            for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
+            if (G != nullptr) G[row] = box_best_distance(best) - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
             if (DERIV) {
-                // gradient of the arg-min box (:359-372).  The clamped-axis mask of the reference drops out:
-                // diff has no component along unclamped axes, so d dist/dz_c = sign * diff . dp/dz_c / |diff|
-                // and diff . (w x (p - o) ) = s_c . [p x diff ; diff].
-                const DevBox* bx = boxes + minIdx;
-                M3 Rb;
+                const SV Wr = box_gradient_wrench(boxes + best.idx, best, point, w0);
 #pragma unroll
-                for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
-                const V3 dw = mul(Rb, bdl);
-                const double scale = (bd2 > 1e-12) ? bsign * w0 / sqrt(bd2) : 0.0;
-                const SV Wr = SV{cross(point, dw), dw};
+                for (int c = 0; c < NV; c++) sl[KL_X + sp * NV + c] = (c < jid) ? dot(lds_sv(sl + KL_S + c * 6), Wr) : 0.0;
+            }
+        }
+        if (split_tail) {
+#pragma unroll 1
+            for (int sp = full; sp < ns; sp++) {
+                const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
+                const int jid = S->joint_id[sp];
+                const V3 point = sphere_centre(sl, S, sp, jid);
+                BoxBest best;
+                best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0x7fffffff;
+                for (int ob = g; ob < O; ob += KG) box_candidate(boxes + ob, ob, point, best);
+                double dist = (best.idx == 0x7fffffff) ? 1e19 : box_best_distance(best);
 #pragma unroll
-                for (int c = 0; c < NV; c++) {
-                    const double d = (c < jid) ? scale * dot(lds_sv(sl + KL_S + c * 6), Wr) : 0.0;
-                    sl[KL_X + sp * NV + c] = d;
+                for (int d = KG / 2; d >= 1; d >>= 1) {
+                    const double od = __shfl_xor(dist, d, KG);
+                    const int oi = __shfl_xor(best.idx, d, KG);
+                    const double o2 = __shfl_xor(best.d2, d, KG), os = __shfl_xor(best.sign, d, KG);
+                    const double ox = __shfl_xor(best.dl.x, d, KG), oy = __shfl_xor(best.dl.y, d, KG), oz = __shfl_xor(best.dl.z, d, KG);
+                    if (od < dist || (od == dist && oi < best.idx)) {
+                        dist = od; best.idx = oi; best.d2 = o2; best.sign = os; best.dl = v3(ox, oy, oz);
+                    }
+                }
+                if (g == 0 && G != nullptr) G[row] = dist - S->radius[sp];
+                if (DERIV) {  // lane c = column c, with its own joint axis still in registers
+                    const SV Wr = box_gradient_wrench(boxes + best.idx, best, point, w0);
+                    if (own) sl[KL_X + sp * NV + g] = (g < jid) ? dot(s, Wr) : 0.0;
                 }
             }
         }
