@@ -20,24 +20,33 @@
 #include "digit_kernel.h"
 #include "legged_kernel.h"
 
-#define PL_WAVES 2   // wavefronts per decision vector: each takes every other manifold direction
+#define PL_WAVES 4   // wavefronts per decision vector: 0 = tree phases, 1 = d v-/d q, all = the small products and the rows
 #define PL_BLOCK (64 * PL_WAVES)
-// LDS map of legged_period_kernel (doubles)
-#define PL_LOC 0                                   // [nv][16] local joint transform: X (9), t (3), axis (3), prismatic flag
-#define PL_S (PL_LOC + RAPTOR_MAX_NV * 16)         // [nv][6] world-frame joint axes, by lane
-#define PL_DV (PL_S + RAPTOR_MAX_NV * 6)           // by lane: v+ - v-, v+, v-
-#define PL_VP (PL_DV + RAPTOR_MAX_NV)
-#define PL_VM (PL_VP + RAPTOR_MAX_NV)
-#define PL_U (PL_VM + RAPTOR_MAX_NV)                // [PL_WAVES][2][nv] per wavefront: u, Vq of the direction it works on
-#define PL_H (PL_U + PL_WAVES * 2 * RAPTOR_MAX_NV)  // [nv][nv] crba(q-) incl. armature, by model joint
-#define PL_JA (PL_H + RAPTOR_MAX_NV * RAPTOR_MAX_NV)  // [nd][nv] constraint Jacobian after the swap
-#define PL_D1 (PL_JA + 24 * RAPTOR_MAX_NV)         // [nv][ni] coefficient of B_k(T) in the g1 rows
-#define PL_D2 (PL_D1 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nv][ni] coefficient of dB_k(T)
-#define PL_G2 (PL_D2 + RAPTOR_MAX_NV * RAPTOR_LEG_MAX_IND)  // [nd][ni] D_t (J v+)
-#define PL_W (PL_G2 + 24 * RAPTOR_LEG_MAX_IND)     // [4][16] B, dB of the first sample, B, dB of the last
+// LDS map of legged_period_kernel<NVM, NDM> (doubles): NVM / NDM = compiled bounds on nv / n_dep (18 / 6 for Talos and G1,
+// 36 / 24 for Digit), so that the small robots keep several decision vectors per CU in flight
+#define PL_HS (NVM + 1)                            // padded row stride of H and A (per-lane rows on distinct LDS banks)
+#define PL_TS RAPTOR_LEG_MAX_IND                   // row stride of the [joint][direction] tables
+#define PL_LOC 0                                   // [nv][16] local joint transform (phases 0-A); then [nv][12] psi, X per lane
+#define PL_S (PL_LOC + NVM * 18)                   // [nv][6] world-frame joint axes, by lane
+#define PL_D1 PL_LOC                               // [nv][ni] coefficient of B_k(T) in the g1 rows   } written after the tree
+#define PL_D2 (PL_LOC + NVM * PL_TS)               // [nv][ni] coefficient of dB_k(T)                  } phases are over
+#define PL_DV (PL_S + NVM * 6)                     // by lane: v+ - v-, v+, v-
+#define PL_VP (PL_DV + NVM)
+#define PL_VM (PL_VP + NVM)
+#define PL_H (PL_VM + NVM)                         // [nv][HS] crba(q-) incl. armature, by model joint
+#define PL_JA (PL_H + NVM * PL_HS)                 // [nd][nv] constraint Jacobian after the swap
+#define PL_A (PL_JA + NDM * NVM)                   // [nv + 6][HS] d(H dv - J^T lambda)/dq, then the six rows d(J_foot v+)/dq
+#define PL_ZEROED (NVM * PL_HS + NDM * NVM + (NVM + 6) * PL_HS)
+#define PL_PF (PL_A + (NVM + 6) * PL_HS)           // [nv][TS] joint rates along the manifold directions (identity rows + P_dep)
+#define PL_VQ (PL_PF + NVM * PL_TS)                // [nv][TS] d v- / d q_t at fixed actuator rates
+#define PL_G2 (PL_VQ + NVM * PL_TS)                // [nd][ni] D_t (J v+)
+#define PL_W (PL_G2 + NDM * PL_TS)                 // [4][16] B, dB of the first sample, B, dB of the last
 #define PL_C5 (PL_W + 64)                          // [7][6] d g5 / d lambda.tail(6)
-#define PL_E (PL_C5 + 42)                          // [3][3] E = d rpy / d omega at the contact frame; then [3][3] A_ij = m . T_ij,
-#define PL_TOTAL (PL_E + 27)                       // [3][3] B_j = sum_i T_ij omega+_i   (T_ij = d_rpy_rates(R_c, e_i, e_j))
+#define PL_E (PL_C5 + 42)                          // [3][3] E = d rpy / d omega at the contact frame; [3][3] A9_ij = m . T_ij;
+#define PL_TMP (PL_E + 27)                         // [3][3] Bm = sum_i T_ij omega+_i   (T_ij = d_rpy_rates(R_c, e_i, e_j))
+#define PL_PATH (PL_TMP + 27)                      // bytes: [nv][2][RAPTOR_LEG_MAX_DEPTH] lanes of this lane's path, their model joints
+#define PL_TOTAL (PL_PATH + NVM * 2 * RAPTOR_LEG_MAX_DEPTH / 8)
+constexpr int period_lds_doubles(int NVM, int NDM) { return PL_TOTAL; }
 
 // directional derivative of rpy_rates(R, w) with respect to R along dR = [ww]x R (w fixed): the second-order part of
 // ForwardKinematicsSolver::getRPYHessian (ForwardKinematics.cpp:445-498)
@@ -154,19 +163,19 @@ __global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* _
     }
 }
 
-template <bool DERIV>
-__global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
-                                                           const DevLegged* __restrict__ Q, const DevPeriod* __restrict__ P,
-                                                           const double* __restrict__ basis, const DevLayout L,
-                                                           const double* __restrict__ Z, const double* __restrict__ core,
-                                                           const double* __restrict__ loops,
-                                                           const double* __restrict__ ploops, double* __restrict__ G,
-                                                           double* __restrict__ JAC) {
+template <int NVM, int NDM, bool DERIV>
+__global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
+                                                                   const DevLegged* __restrict__ Q, const DevPeriod* __restrict__ P,
+                                                                   const double* __restrict__ basis, const DevLayout L,
+                                                                   const double* __restrict__ Z, const double* __restrict__ core,
+                                                                   const double* __restrict__ loops,
+                                                                   const double* __restrict__ ploops, double* __restrict__ G,
+                                                                   double* __restrict__ JAC) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int g = tid & 63;
-    const int wv = tid >> 6;       // every wavefront repeats the cheap phases 0-B in registers; wavefront 0 owns the stores
-    const bool lead = wv == 0;
+    const int wv = tid >> 6;
+    const bool lead = wv == 0;     // wavefront 0 walks the tree (lane = joint in DFS order)
     const long long b = blockIdx.x;
     const int nj = P->nj, ni = Q->ni, nd = Q->nd, nv = Q->nv, K = Q->K, n = L.n, N = T->N;
     const int ncl = nd - 6;  // closure rows
@@ -180,23 +189,30 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
     const int gj = on ? g : 0;
     const int jnt = P->lane_joint[gj];
     const int gend = on ? P->end[gj] : g;
-    const int depth = on ? P->depth[gj] : 0;
+    const int depth = (on && lead) ? P->depth[gj] : 0;
     const int nf = P->new_foot_lane, of = P->old_foot_lane;
     const double arm = on ? M->armature[jnt] : 0.0;
-    const int myloop = on ? P->joint_loop[jnt] : -1;
-    const int myvar = on ? P->joint_var[jnt] : 0;
-    const double* mypl = (myloop >= 0) ? pl + P->loop_off[myloop] : nullptr;
-    const int mynvl = (myloop >= 0) ? P->loop_nvl[myloop] : 0, mynr = (myloop >= 0) ? P->loop_nr[myloop] : 0,
-              mynx = (myloop >= 0) ? P->loop_nx[myloop] : 0;
+    const V3 lt = v3(z[cl + nd - 6], z[cl + nd - 5], z[cl + nd - 4]);
+    const V3 lr = v3(z[cl + nd - 3], z[cl + nd - 2], z[cl + nd - 1]);
 
     // ---- phase 0: this joint's local transform at q-, the reset velocities; clear the sparse pieces ----
-    for (int k = tid; k < RAPTOR_MAX_NV * RAPTOR_MAX_NV + 24 * RAPTOR_MAX_NV; k += PL_BLOCK) lds[PL_H + k] = 0.0;  // H and JA are adjacent
-    for (int k = tid; k < 24 * RAPTOR_LEG_MAX_IND; k += PL_BLOCK) lds[PL_G2 + k] = 0.0;
-    const double qm = on ? recN[Q->c_q + jnt] : 0.0;
-    const double vm = on ? recN[Q->c_v + jnt] : 0.0;
-    const double vpl = on ? z[cv + jnt] : 0.0;
-    const double dvj = vpl - vm;
+    for (int k = tid; k < PL_ZEROED; k += PL_BLOCK) lds[PL_H + k] = 0.0;  // H, JA and A are adjacent
+    for (int k = tid; k < NDM * PL_TS; k += PL_BLOCK) lds[PL_G2 + k] = 0.0;
+    // the walks below are chains of dependent LDS reads: keep their indices in LDS too (one byte each), not in global tables
+    unsigned char* pathL = reinterpret_cast<unsigned char*>(lds + PL_PATH) + gj * 2 * RAPTOR_LEG_MAX_DEPTH;
+    unsigned char* pathJ = pathL + RAPTOR_LEG_MAX_DEPTH;
+    const unsigned char* pathOf = reinterpret_cast<unsigned char*>(lds + PL_PATH) + of * 2 * RAPTOR_LEG_MAX_DEPTH;
+    double vpl = 0.0, dvj = 0.0;
     if (on && lead) {
+        for (int d = 0; d < depth; d++) {
+            const int k = P->path[gj][d];
+            pathL[d] = (unsigned char)k;
+            pathJ[d] = (unsigned char)P->lane_joint[k];
+        }
+        const double qm = recN[Q->c_q + jnt];
+        const double vm = recN[Q->c_v + jnt];
+        vpl = z[cv + jnt];
+        dvj = vpl - vm;
         double sq, cq;
         sincos(qm, &sq, &cq);
         M3 Pm, X;
@@ -218,9 +234,31 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
         lds[PL_VP + g] = vpl;
         lds[PL_VM + g] = vm;
     }
+    if (DERIV && wv == 1 && on) {
+        // wavefront 1, meanwhile: joint rates along every manifold direction (identity rows + P_dep of the last sample) and
+        // d v-/d q_t of the closed-loop joints (Y2 contracted with the drivers' rates)
+        const int ti = Q->joint_ind[jnt], dd = Q->joint_dep[jnt];
+        double* pf = lds + PL_PF + jnt * PL_TS;
+        double* vq = lds + PL_VQ + jnt * PL_TS;
+        if (ti >= 0) {
+            for (int t = 0; t < ni; t++) { pf[t] = (ti == t) ? 1.0 : 0.0; vq[t] = 0.0; }
+        } else if (dd < 6) {
+            for (int t = 0; t < ni; t++) { pf[t] = recN[Q->c_P + t * 6 + dd]; vq[t] = 0.0; }
+        } else {
+            const int c0 = Q->dep_col[dd][0], c1 = Q->dep_col[dd][1];
+            const double* p2 = recN + Q->c_Pl + (dd - 6) * 2;
+            const double* y = loops + ((size_t)(b * N + N - 1) * Q->nrec + P->joint_rec[jnt]) * DIGIT_REC;
+            const double va = recN[Q->c_v + Q->ind_joint[c0]];
+            const double vb = (c1 >= 0) ? recN[Q->c_v + Q->ind_joint[c1]] : 0.0;
+            for (int t = 0; t < ni; t++) {
+                pf[t] = (t == c0) ? p2[0] : ((t == c1) ? p2[1] : 0.0);
+                vq[t] = (t == c0) ? y[3] * va + y[4] * vb : ((t == c1) ? y[4] * va + y[5] * vb : 0.0);
+            }
+        }
+    }
     __syncthreads();
 
-    // ---- phase A: world-frame pose and joint axis (walk from the world down to this joint) ----
+    // ---- phase A (wavefront 0): world-frame pose and joint axis (walk from the world down to this joint) ----
     M3 Rw;
 #pragma unroll
     for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
     SV s = sv_zero();
 #pragma unroll 1
     for (int d = 0; d < depth; d++) {
-        const double* x = lds + PL_LOC + P->path[gj][d] * 16;
+        const double* x = lds + PL_LOC + pathL[d] * 16;
         const M3 R = mul(Rw, x);
         const V3 o = ow + mul(Rw, v3(x[9], x[10], x[11]));
         const V3 axw = mul(Rw, v3(x[12], x[13], x[14]));
@@ -237,246 +275,290 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
         ow = o;
     }
     if (on && lead) lds_put(lds + PL_S + g * 6, s);
-    InertiaO I;
-    {
-        Inertia Ic;
-        const V3 c = ow + mul(Rw, v3(M->lever[jnt][0], M->lever[jnt][1], M->lever[jnt][2]));
-        rotate_inertia(Rw, M->Ic[jnt], Ic);
-        const double m = on ? M->mass[jnt] : 0.0;
-        const double keep = on ? 1.0 : 0.0;
-        I.m = m;
-        I.hv = c * m;
-        const double cc = dot(c, c);
-        I.xx = keep * Ic.xx + m * (cc - c.x * c.x);
-        I.yy = keep * Ic.yy + m * (cc - c.y * c.y);
-        I.zz = keep * Ic.zz + m * (cc - c.z * c.z);
-        I.xy = keep * Ic.xy - m * c.x * c.y;
-        I.xz = keep * Ic.xz - m * c.x * c.z;
-        I.yz = keep * Ic.yz - m * c.y * c.z;
-    }
     __syncthreads();
 
-    // ---- phase B: values.  a = sum s_j (v+ - v-)_j, V+ = sum s_j v+_j along the path; contact point after the swap ----
-    SV aD = sv_zero(), Vp = sv_zero();
+    if (DERIV && wv == 1 && g < ni) {
+        // ---- wavefront 1, lane = direction t: d v-/d q_t of the floating base.  The old stance foot stays planted along the
+        // direction: sum_base s_b Vq_b = -(sum over its path of (w_j x s_j) v-_j + s_j Vq_j), w_j the twist per unit q_t ----
+        const int t = g;
+        const int dof = P->depth[of];
+        SV w = sv_zero(), r = sv_zero();
 #pragma unroll 1
-    for (int d = 0; d < depth; d++) {
-        const int j = P->path[gj][d];
-        const SV sj = lds_sv(lds + PL_S + j * 6);
-        aD = aD + sj * lds[PL_DV + j];
-        Vp = Vp + sj * lds[PL_VP + j];
-    }
-    M3 Rc;
-    V3 pc;
-    {
-        const M3 Rmine = mul(Rw, P->endR);
-        const V3 pmine = ow + mul(Rw, v3(P->endp[0], P->endp[1], P->endp[2]));
-#pragma unroll
-        for (int k = 0; k < 9; k++) Rc.m[k] = __shfl(Rmine.m[k], nf, 64);
-        pc = v3(__shfl(pmine.x, nf, 64), __shfl(pmine.y, nf, 64), __shfl(pmine.z, nf, 64));
-    }
-    const V3 lt = v3(z[cl + nd - 6], z[cl + nd - 5], z[cl + nd - 4]);
-    const V3 lr = v3(z[cl + nd - 3], z[cl + nd - 2], z[cl + nd - 1]);
-    const V3 wp = v3(__shfl(Vp.a.x, nf, 64), __shfl(Vp.a.y, nf, 64), __shfl(Vp.a.z, nf, 64));  // omega+ of the new stance foot
-    // E = d rpy / d omega at the contact frame, and the bilinear form T_ij = d_rpy_rates(R_c, e_i, e_j) contracted with the
-    // two fixed vectors it meets (m = lambda's moment part, omega+): nine lanes evaluate one (i, j) pair each, once
-    if (lead && g < 9) {
-        const int i = g / 3, j = g - 3 * i;
-        const V3 ei = v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0);
-        const V3 ej = v3(j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0);
-        const V3 Tij = d_rpy_rates(Rc, ei, ej);
-        lds[PL_E + 9 + g] = dot(lr, Tij);                  // A[i][j]
-        const double wi = (i == 0) ? wp.x : ((i == 1) ? wp.y : wp.z);
-        lds[PL_E + 18 + g] = 0.0;
-        // B[:, j] += T_ij * omega+_i : three lanes (i = 0..2) per j, summed below through LDS
-        lds[PL_LOC + g * 3] = Tij.x * wi; lds[PL_LOC + g * 3 + 1] = Tij.y * wi; lds[PL_LOC + g * 3 + 2] = Tij.z * wi;
-        if (j == 0) {  // E[:, i] = rpy_rates(R_c, e_i)
-            const V3 Ei = rpy_rates(Rc, ei);
-            lds[PL_E + i] = Ei.x; lds[PL_E + 3 + i] = Ei.y; lds[PL_E + 6 + i] = Ei.z;
+        for (int d = 0; d < dof; d++) {
+            const int k = pathOf[d];
+            const int jk = pathOf[RAPTOR_LEG_MAX_DEPTH + d];
+            const SV sj = lds_sv(lds + PL_S + k * 6);
+            w = w + sj * lds[PL_PF + jk * PL_TS + t];
+            r = r + crm(w, sj) * lds[PL_VM + k] + sj * lds[PL_VQ + jk * PL_TS + t];
         }
+        // the floating base (validated at set-up): three prismatic joints along orthonormal axes, then three revolute joints
+        SV sb[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) sb[q] = lds_sv(lds + PL_S + pathOf[q] * 6);
+        const V3 ra = -r.a;
+        const V3 c45 = cross(sb[4].a, sb[5].a);
+        const double det = dot(sb[3].a, c45);
+        const double x3 = dot(ra, c45) / det;
+        const double x4 = dot(sb[3].a, cross(ra, sb[5].a)) / det;
+        const double x5 = dot(sb[3].a, cross(sb[4].a, ra)) / det;
+        const V3 rl = -r.l - sb[3].l * x3 - sb[4].l * x4 - sb[5].l * x5;
+        const double xs[6] = {dot(sb[0].l, rl), dot(sb[1].l, rl), dot(sb[2].l, rl), x3, x4, x5};
+#pragma unroll
+        for (int q = 0; q < 6; q++) lds[PL_VQ + pathOf[RAPTOR_LEG_MAX_DEPTH + q] * PL_TS + t] = xs[q];
     }
-    __syncthreads();
-    if (lead && g < 9) {  // B[r][j] = sum_i T_ij[r] omega+_i
-        const int r = g / 3, j = g - 3 * r;
-        lds[PL_E + 18 + g] = lds[PL_LOC + (0 * 3 + j) * 3 + r] + lds[PL_LOC + (1 * 3 + j) * 3 + r] + lds[PL_LOC + (2 * 3 + j) * 3 + r];
-    }
-    __syncthreads();
-    const double* Em = lds + PL_E;
-#define E_MUL(q_) v3(Em[0] * (q_).x + Em[1] * (q_).y + Em[2] * (q_).z, Em[3] * (q_).x + Em[4] * (q_).y + Em[5] * (q_).z, Em[6] * (q_).x + Em[7] * (q_).y + Em[8] * (q_).z)
-    const SV Ia = applyO(I, aD);
-    SV f = Ia;
-    if (g == nf) {  // - J_foot^T lambda.tail(6) is a wrench at the contact point: [p_c x f + E^T m ; f]
+
+    if (lead) {
+        // ---- phase B (wavefront 0): values.  a = sum s_j (v+ - v-)_j, V+ = sum s_j v+_j along the path ----
+        InertiaO I;
+        {
+            Inertia Ic;
+            const V3 c = ow + mul(Rw, v3(M->lever[jnt][0], M->lever[jnt][1], M->lever[jnt][2]));
+            rotate_inertia(Rw, M->Ic[jnt], Ic);
+            const double m = on ? M->mass[jnt] : 0.0;
+            const double keep = on ? 1.0 : 0.0;
+            I.m = m;
+            I.hv = c * m;
+            const double cc = dot(c, c);
+            I.xx = keep * Ic.xx + m * (cc - c.x * c.x);
+            I.yy = keep * Ic.yy + m * (cc - c.y * c.y);
+            I.zz = keep * Ic.zz + m * (cc - c.z * c.z);
+            I.xy = keep * Ic.xy - m * c.x * c.y;
+            I.xz = keep * Ic.xz - m * c.x * c.z;
+            I.yz = keep * Ic.yz - m * c.y * c.z;
+        }
+        SV aD = sv_zero(), Vp = sv_zero();
+#pragma unroll 1
+        for (int d = 0; d < depth; d++) {
+            const int j = pathL[d];
+            const SV sj = lds_sv(lds + PL_S + j * 6);
+            aD = aD + sj * lds[PL_DV + j];
+            Vp = Vp + sj * lds[PL_VP + j];
+        }
+        M3 Rc;
+        V3 pc;
+        {
+            const M3 Rmine = mul(Rw, P->endR);
+            const V3 pmine = ow + mul(Rw, v3(P->endp[0], P->endp[1], P->endp[2]));
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rc.m[k] = __shfl(Rmine.m[k], nf, 64);
+            pc = v3(__shfl(pmine.x, nf, 64), __shfl(pmine.y, nf, 64), __shfl(pmine.z, nf, 64));
+        }
+        SV Vpn;  // V+ of the new stance foot
+        Vpn.a = v3(__shfl(Vp.a.x, nf, 64), __shfl(Vp.a.y, nf, 64), __shfl(Vp.a.z, nf, 64));
+        Vpn.l = v3(__shfl(Vp.l.x, nf, 64), __shfl(Vp.l.y, nf, 64), __shfl(Vp.l.z, nf, 64));
+        // E = d rpy / d omega at the contact frame, and the bilinear form T_ij = d_rpy_rates(R_c, e_i, e_j) contracted with
+        // the two fixed vectors it meets (m = lambda's moment part, omega+): nine lanes evaluate one (i, j) pair each, once
+        if (g < 9) {
+            const int i = g / 3, j = g - 3 * i;
+            const V3 ei = v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0);
+            const V3 ej = v3(j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0);
+            const V3 Tij = d_rpy_rates(Rc, ei, ej);
+            lds[PL_E + 9 + g] = dot(lr, Tij);  // A9[i][j]
+            const double wi = (i == 0) ? Vpn.a.x : ((i == 1) ? Vpn.a.y : Vpn.a.z);
+            lds[PL_TMP + g * 3] = Tij.x * wi; lds[PL_TMP + g * 3 + 1] = Tij.y * wi; lds[PL_TMP + g * 3 + 2] = Tij.z * wi;
+            if (j == 0) {  // E[:, i] = rpy_rates(R_c, e_i)
+                const V3 Ei = rpy_rates(Rc, ei);
+                lds[PL_E + i] = Ei.x; lds[PL_E + 3 + i] = Ei.y; lds[PL_E + 6 + i] = Ei.z;
+            }
+        }
+        wave_sync();
+        double bm = 0.0;
+        if (g < 9) {  // Bm[r][j] = sum_i T_ij[r] omega+_i
+            const int r = g / 3, j = g - 3 * r;
+            bm = lds[PL_TMP + (0 * 3 + j) * 3 + r] + lds[PL_TMP + (1 * 3 + j) * 3 + r] + lds[PL_TMP + (2 * 3 + j) * 3 + r];
+        }
+        wave_sync();
+        if (g < 9) lds[PL_E + 18 + g] = bm;
+        wave_sync();
+        const double* Em = lds + PL_E;
+#define M3MUL(m_, q_) v3((m_)[0] * (q_).x + (m_)[1] * (q_).y + (m_)[2] * (q_).z, (m_)[3] * (q_).x + (m_)[4] * (q_).y + (m_)[5] * (q_).z, (m_)[6] * (q_).x + (m_)[7] * (q_).y + (m_)[8] * (q_).z)
+        // - J_foot^T lambda.tail(6) is a wrench at the contact point: W = [p_c x f + E^T m ; f]
         const V3 Etl = v3(Em[0] * lr.x + Em[3] * lr.y + Em[6] * lr.z, Em[1] * lr.x + Em[4] * lr.y + Em[7] * lr.z,
                           Em[2] * lr.x + Em[5] * lr.y + Em[8] * lr.z);
-        f = f - SV{cross(pc, lt) + Etl, lt};
-    }
-    SV F = f;
-    InertiaO IC = I;
-    const int src = gend & 63;
+        const SV Wc = SV{cross(pc, lt) + Etl, lt};
+        SV F = applyO(I, aD);
+        if (g == nf) F = F - Wc;
+        InertiaO IC = I;
+        const int src = gend & 63;
 #define SCAN(x) { const double y_ = __shfl_down(x, d, 64); if (take) x += y_; }
 #define CUT(x) { const double y_ = __shfl(x, src, 64); x -= y_; }
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const bool take = (g + d) < 64;
-        SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
-        SCAN(IC.m) SCAN(IC.hv.x) SCAN(IC.hv.y) SCAN(IC.hv.z)
-        SCAN(IC.xx) SCAN(IC.xy) SCAN(IC.xz) SCAN(IC.yy) SCAN(IC.yz) SCAN(IC.zz)
-    }
-    CUT(F.a.x) CUT(F.a.y) CUT(F.a.z) CUT(F.l.x) CUT(F.l.y) CUT(F.l.z)
-    CUT(IC.m) CUT(IC.hv.x) CUT(IC.hv.y) CUT(IC.hv.z)
-    CUT(IC.xx) CUT(IC.xy) CUT(IC.xz) CUT(IC.yy) CUT(IC.yz) CUT(IC.zz)
-
-    if (on && lead) {
-        // (1) H (v+ - v-) - J^T lambda   (:88-98)
-        double val = dot(s, F) + arm * dvj;
-        if (myloop >= 0) val -= mypl[mynr * mynvl + mynr + myvar];
-        if (G != nullptr) G[rowbase + jnt] = val;
-        // crba(q-): H_kc = s_c . I^C_k s_k for c on the path of k   (:89-96; armature on the diagonal as Pinocchio >= 3 has it)
-        const SV IS = applyO(IC, s);
-#pragma unroll 1
-        for (int d = 0; d < depth; d++) {
-            const int c = P->path[gj][d];
-            const int jc = P->lane_joint[c];
-            const double h = dot(lds_sv(lds + PL_S + c * 6), IS) + ((c == g) ? arm : 0.0);
-            lds[PL_H + jnt * nv + jc] = h;
-            lds[PL_H + jc * nv + jnt] = h;
-        }
-        // stance-foot rows of J after the swap (TalosDynamicsConstraints.cpp:264-279): translation and RPY Jacobian columns
-        if (g <= nf && nf < gend) {
-            const V3 Jt = s.l + cross(s.a, pc);
-            const V3 Jr = E_MUL(s.a);
-            double* ja = lds + PL_JA + ncl * nv + jnt;
-            ja[0] = Jt.x; ja[nv] = Jt.y; ja[2 * nv] = Jt.z;
-            ja[3 * nv] = Jr.x; ja[4 * nv] = Jr.y; ja[5 * nv] = Jr.z;
-        }
-        // closure rows of J (Digit): columns of the loop joints only
-        if (myloop >= 0) {
-            const int row0 = P->loop_row0[myloop];
-            for (int r = 0; r < mynr; r++) lds[PL_JA + (row0 + r) * nv + jnt] = mypl[r * mynvl + myvar];
-        }
-    }
-    if (G != nullptr && lead) {
-        // (2) J v+   (:119-120)
-        if (g == nf) {
-            const V3 lin = Vp.l + cross(Vp.a, pc);
-            const V3 rot = E_MUL(Vp.a);
-            double* o = G + rowbase + nv + ncl;
-            o[0] = lin.x; o[1] = lin.y; o[2] = lin.z; o[3] = rot.x; o[4] = rot.y; o[5] = rot.z;
-        }
-        if (g < ncl) {
-            const int l = P->row_loop[g];
-            G[rowbase + nv + g] = pl[P->loop_off[l] + P->loop_nr[l] * P->loop_nvl[l] + P->row_local[g]];
-        }
-        // (3) position reset, (4) velocity reset   (:130-144)
-        if (g < ni) {
-            const int a = P->id1[g], c = P->id2[g];
-            G[rowbase + nv + nd + g] = rec0[Q->c_q + a] + P->sign * recN[Q->c_q + c];
-            G[rowbase + nv + nd + ni + g] = rec0[Q->c_v + a] + P->sign * z[cv + c];
-        }
-        // (5) contact constraints on the impact impulse   (:152-179)
-        if (g == 0) {
-            double* o = G + rowbase + nv + nd + 2 * ni;
-            const double fz = lt.z;
-            o[0] = fz;
-            o[1] = lt.x * lt.x + lt.y * lt.y - (Q->mu * fz) * (Q->mu * fz);
-            o[2] = lr.z * lr.z - (Q->gamma * fz) * (Q->gamma * fz);
-            o[3] = lr.x - Q->Lx * fz;
-            o[4] = -Q->Lx * fz - lr.x;
-            o[5] = lr.y - Q->Ly * fz;
-            o[6] = -Q->Ly * fz - lr.y;
-        }
-    }
-    if (!DERIV) return;
-
-    // ---- phase C: the twelve manifold directions ----
-    double* myU = lds + PL_U + wv * 2 * RAPTOR_MAX_NV;
-    double* myVQ = myU + RAPTOR_MAX_NV;
-#pragma unroll 1
-    for (int t = wv; t < ni; t += PL_WAVES) {
-        {   // this joint's rate along the direction, and d v-/d q_t of a closed-loop joint (Y2 contracted with the drivers' rates)
-            double u = 0.0, vq = 0.0;
-            if (on) {
-                const int ti = Q->joint_ind[jnt], dd = Q->joint_dep[jnt];
-                if (ti >= 0) u = (ti == t) ? 1.0 : 0.0;
-                else if (dd < 6) u = recN[Q->c_P + t * 6 + dd];
-                else {
-                    const int c0 = Q->dep_col[dd][0], c1 = Q->dep_col[dd][1];
-                    const double* p2 = recN + Q->c_Pl + (dd - 6) * 2;
-                    u = (t == c0) ? p2[0] : ((t == c1) ? p2[1] : 0.0);
-                    const double* y = loops + ((size_t)(b * N + N - 1) * Q->nrec + P->joint_rec[jnt]) * DIGIT_REC;
-                    const double va = recN[Q->c_v + Q->ind_joint[c0]];
-                    const double vb = (c1 >= 0) ? recN[Q->c_v + Q->ind_joint[c1]] : 0.0;
-                    if (t == c0) vq = y[3] * va + y[4] * vb;
-                    else if (t == c1) vq = y[4] * va + y[5] * vb;
-                }
-                myU[g] = u;
-                myVQ[g] = vq;
-            }
-        }
-        wave_sync();
-        SV w = sv_zero(), CD = sv_zero(), Cp = sv_zero(), Cm = sv_zero(), Sq = sv_zero();
-#pragma unroll 1
-        for (int d = 0; d < depth; d++) {
-            const int j = P->path[gj][d];
-            const SV sj = lds_sv(lds + PL_S + j * 6);
-            w = w + sj * myU[j];
-            const SV c = crm(w, sj);
-            CD = CD + c * lds[PL_DV + j];
-            Cp = Cp + c * lds[PL_VP + j];
-            Cm = Cm + c * lds[PL_VM + j];
-            Sq = Sq + sj * myVQ[j];
-        }
-        // the old stance foot stays planted along the direction: sum_base s_b Vq_b = -(Cm + Sq) at its lane
-        SV rof = Cm + Sq;
-        rof.a.x = __shfl(rof.a.x, of, 64); rof.a.y = __shfl(rof.a.y, of, 64); rof.a.z = __shfl(rof.a.z, of, 64);
-        rof.l.x = __shfl(rof.l.x, of, 64); rof.l.y = __shfl(rof.l.y, of, 64); rof.l.z = __shfl(rof.l.z, of, 64);
-        const SV da = CD - Sq + rof;
-        SV df = crf(w, Ia) - applyO(I, crm(w, aD)) + applyO(I, da);
-        const V3 dpc = w.l + cross(w.a, pc);  // meaningful on the new stance foot's lane
-        if (g == nf) {  // D_t (E^T m)_i = sum_j (m . T_ij) w_j
-            const double* Am = lds + PL_E + 9;
-            const V3 dEtl = v3(Am[0] * w.a.x + Am[1] * w.a.y + Am[2] * w.a.z, Am[3] * w.a.x + Am[4] * w.a.y + Am[5] * w.a.z,
-                               Am[6] * w.a.x + Am[7] * w.a.y + Am[8] * w.a.z);
-            df = df - SV{cross(dpc, lt) + dEtl, v3(0, 0, 0)};
-        }
-        SV dF = on ? df : sv_zero();
-        SV FP = on ? applyO(I, w) : sv_zero();
-#pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const bool take = (g + d) < 64;
-            SCAN(dF.a.x) SCAN(dF.a.y) SCAN(dF.a.z) SCAN(dF.l.x) SCAN(dF.l.y) SCAN(dF.l.z)
-            SCAN(FP.a.x) SCAN(FP.a.y) SCAN(FP.a.z) SCAN(FP.l.x) SCAN(FP.l.y) SCAN(FP.l.z)
+            SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
+            SCAN(IC.m) SCAN(IC.hv.x) SCAN(IC.hv.y) SCAN(IC.hv.z)
+            SCAN(IC.xx) SCAN(IC.xy) SCAN(IC.xz) SCAN(IC.yy) SCAN(IC.yz) SCAN(IC.zz)
         }
-        CUT(dF.a.x) CUT(dF.a.y) CUT(dF.a.z) CUT(dF.l.x) CUT(dF.l.y) CUT(dF.l.z)
-        CUT(FP.a.x) CUT(FP.a.y) CUT(FP.a.z) CUT(FP.l.x) CUT(FP.l.y) CUT(FP.l.z)
+        CUT(F.a.x) CUT(F.a.y) CUT(F.a.z) CUT(F.l.x) CUT(F.l.y) CUT(F.l.z)
+        CUT(IC.m) CUT(IC.hv.x) CUT(IC.hv.y) CUT(IC.hv.z)
+        CUT(IC.xx) CUT(IC.xy) CUT(IC.xz) CUT(IC.yy) CUT(IC.yz) CUT(IC.zz)
+#undef SCAN
+#undef CUT
+        const int myloop = on ? P->joint_loop[jnt] : -1;
+        const int myvar = on ? P->joint_var[jnt] : 0;
+        const double* mypl = (myloop >= 0) ? pl + P->loop_off[myloop] : nullptr;
+        const int mynvl = (myloop >= 0) ? P->loop_nvl[myloop] : 0, mynr = (myloop >= 0) ? P->loop_nr[myloop] : 0;
+        const bool onnf = on && g <= nf && nf < gend;  // the new stance foot hangs below this joint
+        const SV IS = applyO(IC, s);
         if (on) {
-            double d1 = dot(crm(w, s), F) + dot(s, dF) - arm * myVQ[g];
-            if (myloop >= 0) {
-                const double* dj = mypl + mynr * mynvl + mynr + mynvl + mynr * mynx + myvar * mynx;
-                if (t == P->loop_col[myloop][0]) d1 -= dj[0];
-                else if (mynx > 1 && t == P->loop_col[myloop][1]) d1 -= dj[1];
+            // (1) H (v+ - v-) - J^T lambda   (:88-98)
+            double val = dot(s, F) + arm * dvj;
+            if (myloop >= 0) val -= mypl[mynr * mynvl + mynr + myvar];
+            if (G != nullptr) G[rowbase + jnt] = val;
+            // crba(q-): H_kc = s_c . I^C_k s_k for c on the path of k   (:89-96; armature on the diagonal as Pinocchio >= 3 has it)
+#pragma unroll 1
+            for (int d = 0; d < depth; d++) {
+                const int c = pathL[d];
+                const int jc = pathJ[d];
+                const double h = dot(lds_sv(lds + PL_S + c * 6), IS) + ((c == g) ? arm : 0.0);
+                lds[PL_H + jnt * PL_HS + jc] = h;
+                lds[PL_H + jc * PL_HS + jnt] = h;
             }
-            lds[PL_D1 + jnt * ni + t] = d1;
-            lds[PL_D2 + jnt * ni + t] = -(dot(s, FP) + arm * myU[g]);
+            // stance-foot rows of J after the swap (TalosDynamicsConstraints.cpp:264-279): translation and RPY Jacobian columns
+            if (onnf) {
+                const V3 Jt = s.l + cross(s.a, pc);
+                const V3 Jr = M3MUL(Em, s.a);
+                double* ja = lds + PL_JA + ncl * nv + jnt;
+                ja[0] = Jt.x; ja[nv] = Jt.y; ja[2 * nv] = Jt.z;
+                ja[3 * nv] = Jr.x; ja[4 * nv] = Jr.y; ja[5 * nv] = Jr.z;
+            }
+            // closure rows of J (Digit): columns of the loop joints only
+            if (myloop >= 0) {
+                const int row0 = P->loop_row0[myloop];
+                for (int r = 0; r < mynr; r++) lds[PL_JA + (row0 + r) * nv + jnt] = mypl[r * mynvl + myvar];
+            }
         }
-        if (g == nf) {  // D_t (J_foot v+)
-            const V3 lin = Cp.l + cross(Cp.a, pc) + cross(Vp.a, dpc);
-            const double* Bm = lds + PL_E + 18;
-            const V3 rot = v3(Bm[0] * w.a.x + Bm[1] * w.a.y + Bm[2] * w.a.z, Bm[3] * w.a.x + Bm[4] * w.a.y + Bm[5] * w.a.z,
-                              Bm[6] * w.a.x + Bm[7] * w.a.y + Bm[8] * w.a.z) + E_MUL(Cp.a);
-            double* o = lds + PL_G2 + ncl * ni + t;
-            o[0] = lin.x; o[ni] = lin.y; o[2 * ni] = lin.z; o[3 * ni] = rot.x; o[4 * ni] = rot.y; o[5 * ni] = rot.z;
+        if (G != nullptr) {
+            // (2) J v+   (:119-120)
+            if (g == nf) {
+                const V3 lin = Vp.l + cross(Vp.a, pc);
+                const V3 rot = M3MUL(Em, Vp.a);
+                double* o = G + rowbase + nv + ncl;
+                o[0] = lin.x; o[1] = lin.y; o[2] = lin.z; o[3] = rot.x; o[4] = rot.y; o[5] = rot.z;
+            }
+            if (g < ncl) {
+                const int l = P->row_loop[g];
+                G[rowbase + nv + g] = pl[P->loop_off[l] + P->loop_nr[l] * P->loop_nvl[l] + P->row_local[g]];
+            }
+            // (3) position reset, (4) velocity reset   (:130-144)
+            if (g < ni) {
+                const int a = P->id1[g], c = P->id2[g];
+                G[rowbase + nv + nd + g] = rec0[Q->c_q + a] + P->sign * recN[Q->c_q + c];
+                G[rowbase + nv + nd + ni + g] = rec0[Q->c_v + a] + P->sign * z[cv + c];
+            }
+            // (5) contact constraints on the impact impulse   (:152-179)
+            if (g == 0) {
+                double* o = G + rowbase + nv + nd + 2 * ni;
+                const double fz = lt.z;
+                o[0] = fz;
+                o[1] = lt.x * lt.x + lt.y * lt.y - (Q->mu * fz) * (Q->mu * fz);
+                o[2] = lr.z * lr.z - (Q->gamma * fz) * (Q->gamma * fz);
+                o[3] = lr.x - Q->Lx * fz;
+                o[4] = -Q->Lx * fz - lr.x;
+                o[5] = lr.y - Q->Ly * fz;
+                o[6] = -Q->Ly * fz - lr.y;
+            }
         }
-        if (g < ncl) {  // D_t (J_closure v+): only the loop's own drivers move it
+        if (DERIV) {
+            // ---- phase C1 (wavefront 0): per-joint vectors of A = d(H dv - J^T lambda)/dq at fixed dv, lambda:
+            //   psi_k = a_parent(k) x s_k,   X_k = s_k x* W - d_k W (k above the new stance foot),   cq_k = s_k x* F_k + I^C_k psi_k + X_k
+            //   A[j][k] = IS_j . psi_k + [foot below j] s_j . X_k  (k on the path of j),   A[j][k] = s_j . cq_k  (j strictly above k)
+            // and the columns of d(J_foot v+)/dq.  (scripts/proto_period.py, matrix_form) ----
+            const SV psi = crm(aD - s * dvj, s);
+            SV X = sv_zero();
+            if (onnf) {
+                const double* A9 = lds + PL_E + 9;
+                const double* Bm = lds + PL_E + 18;
+                const V3 spc = s.l + cross(s.a, pc);  // velocity of the contact point per unit rate of this joint
+                X = crf(s, Wc) - SV{cross(spc, lt) + M3MUL(A9, s.a), v3(0, 0, 0)};
+                const SV Cp = crm(s, Vpn - (Vp - s * vpl));
+                const V3 lin = Cp.l + cross(Cp.a, pc) + cross(Vpn.a, spc);
+                const V3 rot = M3MUL(Bm, s.a) + M3MUL(Em, Cp.a);
+                double* bk = lds + PL_A + nv * PL_HS + jnt;
+                bk[0] = lin.x; bk[PL_HS] = lin.y; bk[2 * PL_HS] = lin.z;
+                bk[3 * PL_HS] = rot.x; bk[4 * PL_HS] = rot.y; bk[5 * PL_HS] = rot.z;
+            }
+            const SV cq = crf(s, F) + applyO(IC, psi) + X;
+            wave_sync();  // the local transforms of phase A are dead: their area takes psi, X
+            if (on) {
+                lds_put(lds + PL_LOC + g * 12, psi);
+                lds_put(lds + PL_LOC + g * 12 + 6, X);
+            }
+            wave_sync();
+            // ---- phase C2: rows and columns of A over this joint's path ----
+            if (on) {
+#pragma unroll 1
+                for (int d = 0; d < depth; d++) {
+                    const int k = pathL[d];
+                    const int jk = pathJ[d];
+                    const double* vk = lds + PL_LOC + k * 12;
+                    double a = dot(IS, lds_sv(vk));
+                    if (onnf) a += dot(s, lds_sv(vk + 6));
+                    lds[PL_A + jnt * PL_HS + jk] = a;
+                    if (k != g) lds[PL_A + jk * PL_HS + jnt] = dot(lds_sv(lds + PL_S + k * 6), cq);
+                }
+            }
+        }
+#undef M3MUL
+    }
+    if (!DERIV) return;
+    __syncthreads();
+
+    // ---- phase C3 (all wavefronts): D1 = A Pfull - H Vq, D2 = -H Pfull, D_t(J_foot v+) = B Pfull.  Lane = row (model joint, then
+    // the six foot rows), a wavefront takes every PL_WAVES-th direction; Pfull / Vq reads are LDS broadcasts ----
+    {
+        const bool rowA = g < nv, rowB = g >= nv && g < nv + 6;
+        const double* Arow = lds + PL_A + ((g < nv + 6) ? g : 0) * PL_HS;
+        const double* Hrow = lds + PL_H + (rowA ? g : 0) * PL_HS;
+        const double hs = rowA ? 1.0 : 0.0;
+        constexpr int TPW = (RAPTOR_LEG_MAX_IND + PL_WAVES - 1) / PL_WAVES;
+        double d1[TPW], d2[TPW];
+        int tt[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; i++) {
+            d1[i] = d2[i] = 0.0;
+            tt[i] = (wv + i * PL_WAVES < ni) ? wv + i * PL_WAVES : 0;
+        }
+#pragma unroll 2
+        for (int c = 0; c < nv; c++) {
+            const double a = Arow[c], h = Hrow[c] * hs;
+            const double* pf = lds + PL_PF + c * PL_TS;
+            const double* vq = lds + PL_VQ + c * PL_TS;
+#pragma unroll
+            for (int i = 0; i < TPW; i++) {
+                const double p = pf[tt[i]], q = vq[tt[i]];
+                d1[i] += a * p - h * q;
+                d2[i] -= h * p;
+            }
+        }
+        __syncthreads();  // every read of the tree-phase areas (S, psi, X) is over: D1 / D2 take their place
+        const int rl = rowA ? P->joint_loop[g] : -1;
+#pragma unroll
+        for (int i = 0; i < TPW; i++) {
+            const int t = wv + i * PL_WAVES;
+            if (t >= ni) continue;
+            if (rowA) {
+                double v1 = d1[i];
+                if (rl >= 0) {  // closure part of d(J^T lambda)/dq along the loop's own drivers (digit_period_loops_kernel)
+                    const int nvl = P->loop_nvl[rl], nr = P->loop_nr[rl], nx = P->loop_nx[rl];
+                    const double* dj = pl + P->loop_off[rl] + nr * nvl + nr + nvl + nr * nx + P->joint_var[g] * nx;
+                    if (t == P->loop_col[rl][0]) v1 -= dj[0];
+                    else if (nx > 1 && t == P->loop_col[rl][1]) v1 -= dj[1];
+                }
+                lds[PL_D1 + g * ni + t] = v1;
+                lds[PL_D2 + g * ni + t] = d2[i];
+            } else if (rowB) {
+                lds[PL_G2 + (ncl + g - nv) * ni + t] = d1[i];
+            }
+        }
+        if (lead && g < ncl) {  // D_t (J_closure v+): only the loop's own drivers move it
             const int l = P->row_loop[g];
             const int nx = P->loop_nx[l];
             const double* dj = pl + P->loop_off[l] + P->loop_nr[l] * P->loop_nvl[l] + P->loop_nr[l] + P->loop_nvl[l] + P->row_local[g] * nx;
-            if (t == P->loop_col[l][0]) lds[PL_G2 + g * ni + t] = dj[0];
-            else if (nx > 1 && t == P->loop_col[l][1]) lds[PL_G2 + g * ni + t] = dj[1];
+            lds[PL_G2 + g * ni + P->loop_col[l][0]] = dj[0];
+            if (nx > 1) lds[PL_G2 + g * ni + P->loop_col[l][1]] = dj[1];
         }
-        wave_sync();
     }
-#undef SCAN
-#undef CUT
 
     // ---- phase D: Bernstein weights of the first and last sample, d g5, then the dense rows ----
     if (lead && g < K) {
@@ -534,7 +616,7 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 v[h] = (kind[h] == 0) ? D1s[r * ni + t[h]] * wn0[h] + D2s[r * ni + t[h]] * wn1[h]
-                                      : ((kind[h] == 1) ? Hs[r * nv + a[h]] : -JAs[a[h] * nv + r]);
+                                      : ((kind[h] == 1) ? Hs[r * PL_HS + a[h]] : -JAs[a[h] * nv + r]);
             PUT(v[0], v[1])
         }
         for (int d = 0; d < nd; d++) {  // pg2_pz (:126-127)
@@ -568,7 +650,6 @@ __global__ __launch_bounds__(PL_BLOCK, 2) void legged_period_kernel(const DevMod
         }
 #undef PUT
     }
-#undef E_MUL
 }
 
 #endif

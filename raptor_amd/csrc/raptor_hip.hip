@@ -362,13 +362,17 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
                                p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
             d_pl = p.s_ploops.p;
         }
-        const size_t plds = (size_t)PL_TOTAL * sizeof(double);
-        if (jac)
-            hipLaunchKernelGGL((legged_period_kernel<true>), dim3((unsigned)B), dim3(PL_BLOCK), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
-                               p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, dJ);
-        else
-            hipLaunchKernelGGL((legged_period_kernel<false>), dim3((unsigned)B), dim3(PL_BLOCK), plds, st, p.d_model.p, p.d_traj.p, p.d_leg.p,
-                               p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, nullptr);
+        const bool small = p.hleg.nv <= 18 && p.hleg.nd <= 6;  // Talos / G1; Digit takes the 36 / 24 instance
+#define PERIOD_LAUNCH(NVM_, NDM_, DV_, dJ_)                                                                              \
+    hipLaunchKernelGGL((legged_period_kernel<NVM_, NDM_, DV_>), dim3((unsigned)B), dim3(PL_BLOCK),                          \
+                       (size_t)period_lds_doubles(NVM_, NDM_) * sizeof(double), st, p.d_model.p, p.d_traj.p, p.d_leg.p,    \
+                       p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, dJ_)
+        if (small) {
+            if (jac) PERIOD_LAUNCH(18, 6, true, dJ); else PERIOD_LAUNCH(18, 6, false, nullptr);
+        } else {
+            if (jac) PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, true, dJ); else PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, false, nullptr);
+        }
+#undef PERIOD_LAUNCH
         HIP_CHECK(hipGetLastError());
     }
     if (between) HIP_CHECK(hipEventRecord(between, st));

@@ -80,6 +80,60 @@ def d_rpy_rates(R, w, ww):
     return np.array([(vN0 * D0 - N0 * vD0) / D0 ** 2, dda * vR[0, 2] * dR[0, 2] + da * vdR[0, 2], (vN2 * D2 - N2 * vD2) / D2 ** 2])
 
 
+MATRIX = False
+
+
+def matrix_form(m, n, ni, nd, s, I6, anc, sub, F, W, aD, Vp, dv, vplus, vminus, Pfull, VqLoop, nf, of, pc, Rc, E, lt, lr, H):
+    """D1 = A Pfull - H Vq,  D2 = -H Pfull,  G2_foot = B Pfull with per-joint vectors (what the HIP kernel evaluates):
+         psi_k = a_parent(k) x s_k,  IS_k = I^C_k s_k,  X_k = s_k x* W - D_k W  (k on the new foot's path),
+         cq_k = s_k x* F_k + I^C_k psi_k + X_k,
+         A[j,k] = IS_j . psi_k + [foot in sub(j)] s_j . X_k   (k on the path of j),   A[j,k] = s_j . cq_k   (j strict ancestor of k)."""
+    IC = [sum(I6[l] for l in sub[k]) for k in range(n)]
+    on_nf = [nf in sub[k] for k in range(n)]
+    T = np.array([[d_rpy_rates(Rc, ei, ej) for ej in np.eye(3)] for ei in np.eye(3)])  # T[i][j] = vector
+    A9 = np.array([[lr @ T[i][j] for j in range(3)] for i in range(3)])
+    Bm = np.array([[sum(T[i][j][r] * Vp[nf][i] for i in range(3)) for j in range(3)] for r in range(3)])
+    psi = []; X = []; cq = []; IS = []; Bk = []
+    for k in range(n):
+        par = int(m.parent[k])
+        apk = aD[par] if par >= 0 else np.zeros(6)
+        psi.append(crm(apk, s[k]))
+        IS.append(IC[k] @ s[k])
+        if on_nf[k]:
+            spc = s[k][3:] + np.cross(s[k][:3], pc)
+            DkW = np.concatenate([np.cross(spc, lt) + A9 @ s[k][:3], np.zeros(3)])
+            X.append(crf(s[k], W) - DkW)
+            Vpk = Vp[par] if par >= 0 else np.zeros(6)
+            Cp = crm(s[k], Vp[nf] - Vpk)
+            Bk.append(np.concatenate([Cp[3:] + np.cross(Cp[:3], pc) + np.cross(Vp[nf][:3], spc), Bm @ s[k][:3] + E @ Cp[:3]]))
+        else:
+            X.append(np.zeros(6)); Bk.append(np.zeros(6))
+        # F here already has -W folded in: F_k = sum f - [nf]W, so s x* (F_k + W) + ... - D_k W = s x* F_k + X_k
+        cq.append(crf(s[k], F[k]) + IC[k] @ psi[k] + X[k])
+    A = np.zeros((n, n))
+    for j in range(n):
+        for k in anc[j]:
+            A[j, k] = IS[j] @ psi[k] + (s[j] @ X[k] if on_nf[j] else 0.0)
+            if k != j:
+                A[k, j] = s[k] @ cq[j]
+    # d v-/d q_t: loop joints from Y2 (given), base joints from the planted old stance foot
+    Vq = VqLoop.copy()
+    base = anc[of][:6]
+    Sb = np.column_stack([s[b] for b in base])
+    for t in range(ni):
+        u = Pfull[:, t]
+        w = np.zeros(6); r = np.zeros(6)
+        for j in anc[of]:
+            w = w + s[j] * u[j]
+            r += crm(w, s[j]) * vminus[j] + s[j] * Vq[j, t]
+        Vq[base, t] = np.linalg.solve(Sb, -r)
+    D1 = A @ Pfull - H @ Vq
+    D2 = -H @ Pfull
+    G2 = np.zeros((nd, ni))
+    G2[nd - 6:] = np.column_stack(Bk) @ Pfull
+    return D1, D2, G2
+
+
 def period_block(m, ind, dep, q, vminus, Pfull, Vq, vplus, lam, old_foot, new_foot, endR, endp, id1, id2, sign, q0, v0,
                  w0, wN, cp, loops=None):
     """w0 / wN: Bernstein weights (B, dB) of the first / last sample, shape (2, K).  Returns g (m_p), J (m_p, n)."""
@@ -122,7 +176,10 @@ def period_block(m, ind, dep, q, vminus, Pfull, Vq, vplus, lam, old_foot, new_fo
     J[n + r0:n + nd, cv:cv + n] = Jf
     J[:n, cl + r0:cl + nd] = -Jf.T
     D1 = np.zeros((n, ni)); D2 = np.zeros((n, ni)); G2 = np.zeros((nd, ni))
-    for t in range(ni):
+    if MATRIX:
+        D1, D2, G2 = matrix_form(m, n, ni, nd, s, I6, anc, sub, F, W, aD, Vp, dv, vplus, vminus, Pfull, Vq, f_, old_foot, pc, Rc, E,
+                                 lt, lr, J[:n, cv:cv + n])
+    for t in range(ni if not MATRIX else 0):
         u = Pfull[:, t]; vq = Vq[:, t]
         w = field(u)
         CD = []; Cp = []; Cm = []; Sq = []
@@ -270,4 +327,6 @@ def run(which="talos", N=5, stance="L", verbose=False):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "talos"
+    if len(sys.argv) > 2 and sys.argv[2] == "matrix":
+        MATRIX = True
     print(which, run(which, verbose=True))
