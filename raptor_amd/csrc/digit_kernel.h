@@ -38,13 +38,24 @@ struct DevLoop {
     int rec0;          // first dependent-joint record of this loop in the per-sample loop buffer
     int var_joint[8];  // model joint of each local variable
     int row0;          // first row of the loop's closures in the reference's constraint order (DigitDynamicsConstraints.cpp:579-596)
-    double g_sign[6], g_c0[6], g_lin[6][8], g_pair[6][16];  // initial guess (digit_tables.h)
+    double g_sign[6], g_c0[6], g_lin[6][8], g_quad[6][36];  // initial guess (digit_tables.h); g_quad: upper triangle f_a f_b, a <= b
 };
 struct DevDigit {
     DevLoop loop[2][2];  // [leg][0: knee, 1: toe]
     int pair_idx[16][2];
     int recs_per_sample;  // 18
 };
+
+// Local variable of every chain joint, fixed by the structure of Digit's loops (unknowns first in the order of
+// DIGIT_LOOPS[].depj, then the drivers); the host checks its model-derived tables against these, so that every index into a
+// per-lane array below is a compile-time constant (registers, no scratch).
+//   toe loop : unknowns toe_A_rod 0, A2 1, toe_B_rod 2, B2 3, toe_pitch 4, toe_roll 5; drivers toe_A 6, toe_B 7
+//              closure 0: rod chain toe_A, toe_A_rod, A2 | anchor chain toe_pitch, toe_roll;  closure 1: toe_B, toe_B_rod, B2 | same
+//   knee loop: unknowns achilles_rod 0, ach2 1, tarsus 2; driver knee 3;  rod chain achilles_rod, ach2 | anchor chain knee, tarsus
+__host__ __device__ constexpr int digit_chain_var(bool toe, int closure, bool rod_side, int i) {
+    return toe ? (rod_side ? (closure == 0 ? (i == 0 ? 6 : (i == 1 ? 0 : 1)) : (i == 0 ? 7 : (i == 1 ? 2 : 3))) : (i == 0 ? 4 : 5))
+               : (rod_side ? (i == 0 ? 0 : 1) : (i == 0 ? 3 : 2));
+}
 
 template <int N>
 struct LU {
@@ -117,7 +128,7 @@ template <int NJ>
 struct ChainGeo {
     V3 w[NJ], o[NJ], p;
 };
-template <int NJ>
+template <int NJ, bool TOE, int CLOSURE, bool ROD>
 RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __restrict__ end, const double* th, ChainGeo<NJ>& g) {
     M3 Rw;
 #pragma unroll
@@ -128,7 +139,7 @@ RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __rest
         const M3 A = mul(Rw, J[i].plR);
         V3 o = ow + mul(Rw, v3(J[i].plp[0], J[i].plp[1], J[i].plp[2]));
         double sq, cq;
-        const double q = th[J[i].var];
+        const double q = th[digit_chain_var(TOE, CLOSURE, ROD, i)];
         sincos(q, &sq, &cq);
         M3 R;
         SV s;
@@ -186,11 +197,13 @@ struct LoopSolver {
     ChainGeo<NB> gb[NCL];
     const DevLoop* L;
 
+    static constexpr bool TOE = NCL == 2;
     RD void geometry(const double* th) {
-#pragma unroll
-        for (int c = 0; c < NCL; c++) {
-            chain_geometry<NA>(L->cl[c].A, L->cl[c].endA, th, ga[c]);
-            chain_geometry<NB>(L->cl[c].B, L->cl[c].endB, th, gb[c]);
+        chain_geometry<NA, TOE, 0, true>(L->cl[0].A, L->cl[0].endA, th, ga[0]);
+        chain_geometry<NB, TOE, 0, false>(L->cl[0].B, L->cl[0].endB, th, gb[0]);
+        if (NCL > 1) {
+            chain_geometry<NA, TOE, 1, true>(L->cl[NCL - 1].A, L->cl[NCL - 1].endA, th, ga[NCL - 1]);
+            chain_geometry<NB, TOE, 1, false>(L->cl[NCL - 1].B, L->cl[NCL - 1].endB, th, gb[NCL - 1]);
         }
     }
     RD void residual(double* c) const {
@@ -211,37 +224,25 @@ struct LoopSolver {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 const V3 t = cross(ga[c].w[i], ga[c].p - ga[c].o[i]);
-                const int var = L->cl[c].A[i].var;
-#pragma unroll
-                for (int k = 0; k < NY + NX; k++)
-                    if (k == var) { Jm[3 * c][k] += t.x; Jm[3 * c + 1][k] += t.y; Jm[3 * c + 2][k] += t.z; }
+                const int var = digit_chain_var(TOE, c, true, i);
+                Jm[3 * c][var] += t.x; Jm[3 * c + 1][var] += t.y; Jm[3 * c + 2][var] += t.z;
             }
 #pragma unroll
             for (int i = 0; i < NB; i++) {
                 const V3 t = cross(gb[c].w[i], gb[c].p - gb[c].o[i]);
-                const int var = L->cl[c].B[i].var;
-#pragma unroll
-                for (int k = 0; k < NY + NX; k++)
-                    if (k == var) { Jm[3 * c][k] -= t.x; Jm[3 * c + 1][k] -= t.y; Jm[3 * c + 2][k] -= t.z; }
+                const int var = digit_chain_var(TOE, c, false, i);
+                Jm[3 * c][var] -= t.x; Jm[3 * c + 1][var] -= t.y; Jm[3 * c + 2][var] -= t.z;
             }
         }
     }
     RD void gather(int c, const double* U, double* ua, double* ub) const {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int var = L->cl[c].A[i].var;
-            double x = 0.0;
-#pragma unroll
-            for (int k = 0; k < NY + NX; k++) x = (k == var) ? U[k] : x;
-            ua[i] = x;
+            ua[i] = U[digit_chain_var(TOE, c, true, i)];
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int var = L->cl[c].B[i].var;
-            double x = 0.0;
-#pragma unroll
-            for (int k = 0; k < NY + NX; k++) x = (k == var) ? U[k] : x;
-            ub[i] = x;
+            ub[i] = U[digit_chain_var(TOE, c, false, i)];
         }
     }
     // out += D^2 c [U, V]
@@ -307,17 +308,12 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
             double s = L->g_c0[r];
 #pragma unroll
             for (int k = 0; k < (TOE ? 8 : 4); k++) s += L->g_lin[r][k] * f[k];
-            if (TOE) {
+            if (TOE) {  // the pair terms as a dense upper-triangular quadratic form: constant indices, uniform coefficient loads
+                int k = 0;
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    double fa = 0.0, fb = 0.0;
+                for (int a = 0; a < 8; a++)
 #pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        fa = (t == D->pair_idx[k][0]) ? f[t] : fa;
-                        fb = (t == D->pair_idx[k][1]) ? f[t] : fb;
-                    }
-                    s += L->g_pair[r][k] * fa * fb;
-                }
+                    for (int bb = a; bb < 8; bb++) s += L->g_quad[r][k++] * (f[a] * f[bb]);
             }
             th[r] = L->g_sign[r] * safe_asin(s);
         }

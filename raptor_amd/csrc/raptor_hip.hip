@@ -1103,6 +1103,11 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
                 cl.nA = (int)ra.size(); cl.nB = (int)rb.size();
                 for (size_t k = 0; k < ra.size(); k++) fill_chain_joint(m, ids[ra[k]], var_of(ra[k]), cl.A[k]);
                 for (size_t k = 0; k < rb.size(); k++) fill_chain_joint(m, ids[rb[k]], var_of(rb[k]), cl.B[k]);
+                // the kernels index their per-lane arrays with the compile-time map of digit_kernel.h: it must be this model's
+                for (size_t k = 0; k < ra.size(); k++)
+                    if (cl.A[k].var != digit_chain_var(type == 1, c, true, (int)k)) throw unsupported_error("Digit loop: unexpected rod chain");
+                for (size_t k = 0; k < rb.size(); k++)
+                    if (cl.B[k].var != digit_chain_var(type == 1, c, false, (int)k)) throw unsupported_error("Digit loop: unexpected anchor chain");
                 double an[3] = {lp.anchor[leg][0], lp.anchor[leg][1], lp.anchor[leg][2]};
                 if (type == 0) digit_knee_anchor(leg, an);
                 for (int k = 0; k < 3; k++) { cl.endA[k] = lp.rod[k]; cl.endB[k] = an[k]; }
@@ -1122,7 +1127,12 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
                     const DigitToeGuess& g = DIGIT_TOE_GUESS[leg][r];
                     L.g_sign[r] = g.sign; L.g_c0[r] = g.c0;
                     for (int k = 0; k < 8; k++) L.g_lin[r][k] = g.lin[k];
-                    for (int k = 0; k < 16; k++) L.g_pair[r][k] = g.pair[k];
+                    for (int k = 0; k < 36; k++) L.g_quad[r][k] = 0.0;
+                    for (int k = 0; k < DIGIT_TOE_NPAIR; k++) {
+                        int a = DIGIT_TOE_PAIR[k][0], bq = DIGIT_TOE_PAIR[k][1];
+                        if (a > bq) std::swap(a, bq);
+                        L.g_quad[r][a * 8 - a * (a - 1) / 2 + (bq - a)] += g.pair[k];  // row a of the upper triangle starts at 8a - a(a-1)/2
+                    }
                 } else {
                     const DigitKneeGuess& g = DIGIT_KNEE_GUESS[leg][r];
                     L.g_sign[r] = g.sign; L.g_c0[r] = g.c0;
