@@ -31,9 +31,14 @@
 // LDS layout per sample-eval, in doubles
 #define KL_S 0        // s_j            7 x 6
 #define KL_RO 42      // R, o of up to 4 sphere links   4 x 12
-#define KL_OUT 90     // ptau_pz(i)     7 x 7
-#define KL_X 139      // phase 0 exchange (7 x 5), then IS/BtS (7 x 12) at +35; later sphere rows (ns x 7 <= 140)
-#define KL_STRIDE 282  // >= 279; 564 dwords: the 8 groups of a wave fall on disjoint LDS banks
+#define KL_X 90       // phase 0 exchange (7 x 5), then IS/BtS (7 x 12) at +35; later sphere rows (ns x 7 <= 140)
+// stride per sample-eval (runtime, kinova_lds_stride): 90 + max(119, 7 ns) rounded up to 4 mod 16 doubles, so that the 8 groups
+// of a wave fall on disjoint LDS banks; 17 spheres -> 212 doubles -> 53 KB per workgroup -> three workgroups per CU
+__host__ __device__ inline int kinova_lds_stride(int ns) {
+    int need = KL_X + ((7 * ns > 119) ? 7 * ns : 119);
+    while (need % 16 != 4) need++;
+    return need;
+}
 
 RD void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     const long long e = e0 + eg;
     const int N = T->N;
     const int ns = S->num_spheres;
+    const int KL_STRIDE = kinova_lds_stride(ns);
     double* sl = lds + eg * KL_STRIDE;
 
     if (e < E) {
@@ -289,8 +295,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 lds_put(sl + KL_X + 35 + g * 12 + 6, BtS);
             }
             wave_sync();
-            // ---- phase E: lane g = column g of ptau_pz(i) ----
+            // ---- phase E: lane g = column g of ptau_pz(i); the 7 lanes of a group write one 56-byte row per store, the
+            // groups of a wave (consecutive samples) adjacent blocks of 392 bytes: no LDS staging for these rows ----
             if (own) {
+                double* trow = JAC + (rowbase + L.off_tau + (size_t)i * NV) * NV + g;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     double d;
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                         d = dot(lds_sv(sl + KL_X + 35 + j * 12), gam) + dot(lds_sv(sl + KL_X + 35 + j * 12 + 6), bet);
                         if (j == g) d += M->armature[g] * w2 + M->damping[g] * w1;
                     }
-                    sl[KL_OUT + j * NV + g] = d;
+                    trow[j * NV] = d;
                 }
             }
         }
@@ -379,12 +387,13 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         const size_t rowbase = (size_t)b * L.m;
 #pragma unroll 1
         for (int region = 0; region < 4; region++) {
+            if (region == 2) continue;  // the torque rows were written by phase E
             const int per_e = (region == 3) ? ns * NV : NV * NV;
             const int off = (region == 0) ? L.off_q : (region == 1) ? L.off_qd : (region == 2) ? L.off_tau : L.off_obs;
             const int rows_per_e = (region == 3) ? ns : NV;
             double* dst = JAC + (rowbase + off + (size_t)ia * rows_per_e) * NV;
             const int len = cnt * per_e;
-            const int lds_off = (region == 3) ? KL_X : KL_OUT;
+            const int lds_off = KL_X;
             auto value = [&](int t) -> double {
                 const int el = t / per_e;
                 const int r = t - el * per_e;
