@@ -75,8 +75,9 @@ typedef struct raptor_traj_desc {
     int N;                   /* number of time samples                                         */
     int time_discretization; /* RAPTOR_TIME_*                                                  */
     int Nact;                /* actuated joints driven by the trajectory                       */
-    const double* q0;        /* [Nact] ArmourTrajectoryParameters (ARMOUR_BEZIER only)         */
-    const double* q_d0;      /* [Nact]                                                          */
+    const double* q0;        /* [Nact] ARMOUR_BEZIER: ArmourTrajectoryParameters.  BEZIER: non-null = constrainInitialPosition(q0) */
+    const double* q_d0;      /* [Nact] BEZIER: non-null (with q0) = constrainInitialVelocity(q_d0); each drops Nact variables
+                                (BezierCurves.cpp:39-69, second coefficient row q0 + q_d0 T / 5.0 as written at :86)         */
     const double* q_dd0;     /* [Nact]                                                          */
 } raptor_traj_desc;
 

@@ -360,6 +360,7 @@ struct Trajectory {
     double T = 0;
     std::vector<double> tspan;
     VecX q0, q_d0, q_dd0;
+    int fixed_rows = 0;  // BezierCurves: 1 after constrainInitialPosition, 2 after constrainInitialVelocity
     MatX coefficients;  // (degree+1) x Nact
     VecX Bionomials;
     // results (Trajectories.h:71-83)
@@ -403,6 +404,22 @@ struct Trajectory {
         } else if (type == RAPTOR_TRAJ_BEZIER || type == RAPTOR_TRAJ_POLYNOMIAL) {
             varLength = (degree + 1) * Nact;
             coefficients = MatX(degree + 1, Nact);
+            if (type == RAPTOR_TRAJ_BEZIER) {
+                // BezierCurves::constrainInitialPosition / constrainInitialVelocity (BezierCurves.cpp:39-69), as the single-step
+                // optimizers call them when q0_input / q_d0_input are given (TalosSingleStepOptimizer.cpp:41-46)
+                if (d->q_d0 && !d->q0) throw std::invalid_argument("BezierCurves: initial position must be constrained first");
+                if (d->q0) {
+                    q0.assign(d->q0, d->q0 + Nact);
+                    fixed_rows = 1;
+                    varLength -= Nact;
+                }
+                if (d->q_d0) {
+                    q_d0.assign(d->q_d0, d->q_d0 + Nact);
+                    fixed_rows = 2;
+                    varLength -= Nact;
+                }
+                if (degree + 1 - fixed_rows < 1) throw std::invalid_argument("traj: degree too low for the constrained initial state");
+            }
         } else {
             throw std::invalid_argument("traj: unknown trajectory type");
         }
@@ -469,9 +486,14 @@ struct Trajectory {
                 coefficients(3, j) = qfinal;
             }
         } else {
-            // Utils::reshape is a column-major map (Utils.h:142-146): coefficients(k, j) = z[j*(degree+1)+k]
-            for (int j = 0; j < Nact; j++)
-                for (int k = 0; k <= degree; k++) coefficients(k, j) = z[j * (degree + 1) + k];
+            // Utils::reshape is a column-major map (Utils.h:142-146): coefficients(k, j) = z[j*(degree+1)+k];
+            // BezierCurves.cpp:84-100: the first rows are pinned by the constrained initial state (T / 5.0 as written there)
+            const int free_rows = degree + 1 - fixed_rows;
+            for (int j = 0; j < Nact; j++) {
+                if (fixed_rows >= 1) coefficients(0, j) = q0[j];
+                if (fixed_rows == 2) coefficients(1, j) = q0[j] + q_d0[j] * T / 5.0;
+                for (int k = 0; k < free_rows; k++) coefficients(fixed_rows + k, j) = z[j * free_rows + k];
+            }
         }
         VecX B, dB, ddB;
         for (int x = 0; x < N; x++) {
@@ -498,11 +520,12 @@ struct Trajectory {
                         pq_dd_pz[x](i, i) = ddB[3] + ddB[4] + ddB[5];
                     }
                 } else {
-                    for (int i = 0; i < Nact; i++)  // BezierCurves.cpp:165-169, Polynomials.cpp:75-79
-                        for (int k = 0; k <= degree; k++) {
-                            pq_pz[x](i, i * (degree + 1) + k) = B[k];
-                            pq_d_pz[x](i, i * (degree + 1) + k) = dB[k];
-                            pq_dd_pz[x](i, i * (degree + 1) + k) = ddB[k];
+                    const int free_rows = degree + 1 - fixed_rows;
+                    for (int i = 0; i < Nact; i++)  // BezierCurves.cpp:148-169 (B.tail(...) blocks), Polynomials.cpp:75-79
+                        for (int k = 0; k < free_rows; k++) {
+                            pq_pz[x](i, i * free_rows + k) = B[fixed_rows + k];
+                            pq_d_pz[x](i, i * free_rows + k) = dB[fixed_rows + k];
+                            pq_dd_pz[x](i, i * free_rows + k) = ddB[fixed_rows + k];
                         }
                 }
             }

@@ -29,7 +29,9 @@ struct DevModel {
 // reference's arithmetic (BezierCurves.cpp:117-141, Polynomials.cpp:54-68).
 struct DevTraj {
     int type;       // RAPTOR_TRAJ_*
-    int degree;     // K = degree + 1 basis functions
+    int degree;     // degree + 1 basis functions
+    int K;          // free coefficients per joint = width of the basis tables: degree + 1 minus the rows pinned by
+    int nfixed;     // BezierCurves::constrainInitialPosition / Velocity (0, 1, 2); their contribution is a per-(sample, joint) offset
     int N;          // samples
     int Nact;       // joints driven by the trajectory
     int varLength;  // decision variables (columns of pg_pz)
@@ -62,7 +64,7 @@ struct DevBox {
 #define RAPTOR_LEG_MAX_IND 12
 struct DevLegged {
     int nb;                                   // bodies (links that carry dynamics), body 0 = stance-foot link
-    int ni, nd, nv, K;                        // independent / dependent joints, model nv, degree + 1
+    int ni, nd, nv, K;                        // independent / dependent joints, model nv, free coefficients per joint
     int body_link[RAPTOR_LEG_MAX_BODIES];     // original link (= joint) index whose inertia the body carries
     int body_joint[RAPTOR_LEG_MAX_BODIES];    // original joint connecting the body to its re-rooted parent (-1: root)
     int body_rev[RAPTOR_LEG_MAX_BODIES];      // 1: that joint is crossed child -> parent (axis flips sign)

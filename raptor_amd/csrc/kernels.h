@@ -30,7 +30,7 @@ RD double sign_eps(double v) { return v > 1e-8 ? 1.0 : (v < -1e-8 ? -1.0 : 0.0);
 // ---------------------------------------------------------------------------------------------
 RD void traj_joint(const DevTraj* __restrict__ T, const double* __restrict__ basis, const double* __restrict__ z,
                    int i, int j, double& q, double& qd, double& qdd) {
-    const int K = T->degree + 1;
+    const int K = T->K;
     const double* B0 = basis + (size_t)(i * 3) * K;
     const double* B1 = B0 + K;
     const double* B2 = B1 + K;
@@ -52,6 +52,12 @@ RD void traj_joint(const DevTraj* __restrict__ T, const double* __restrict__ bas
             s1 += ck * B1[k];
             s2 += ck * B2[k];
         }
+        if (T->nfixed > 0) {  // rows pinned by the constrained initial state (BezierCurves.cpp:84-96): table after the basis
+            const double* fx = basis + (size_t)T->N * 3 * K + (size_t)(i * 3) * T->Nact + j;
+            s0 += fx[0];
+            s1 += fx[T->Nact];
+            s2 += fx[2 * T->Nact];
+        }
     }
     q = s0;
     qd = s1;
@@ -67,7 +73,7 @@ RD void column_direction(const DevTraj* __restrict__ T, const double* __restrict
         w1 = wsum[i * 3 + 1];
         w2 = wsum[i * 3 + 2];
     } else {
-        const int K = T->degree + 1;
+        const int K = T->K;
         jd = c / K;
         const int k = c - jd * K;
         const double* B0 = basis + (size_t)(i * 3) * K;

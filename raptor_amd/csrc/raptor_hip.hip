@@ -196,9 +196,16 @@ void fill_traj(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan
         if (d->degree < 1 || d->degree > RAPTOR_MAX_DEGREE) throw std::invalid_argument("traj: degree out of range");
         t.degree = d->degree;
         t.varLength = (d->degree + 1) * d->Nact;
+        if (d->type == RAPTOR_TRAJ_BEZIER) {  // BezierCurves::constrainInitialPosition / Velocity (BezierCurves.cpp:39-69)
+            if (d->q_d0 && !d->q0) throw std::invalid_argument("BezierCurves: initial position must be constrained first");
+            t.nfixed = d->q0 ? (d->q_d0 ? 2 : 1) : 0;
+            t.varLength -= t.nfixed * d->Nact;
+            if (d->degree + 1 - t.nfixed < 1) throw std::invalid_argument("traj: degree too low for the constrained initial state");
+        }
     } else {
         throw std::invalid_argument("traj: unknown trajectory type");
     }
+    t.K = t.degree + 1 - t.nfixed;
     tspan.assign(N, 0.0);
     if (d->time_discretization == RAPTOR_TIME_UNIFORM) {
         for (int i = 0; i < N; i++) tspan[i] = (N == 1) ? T : (0.0 + i * ((T - 0.0) / (N - 1)));
@@ -255,6 +262,25 @@ void fill_traj(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan
             wsum[x * 3 + 1] = dB[3] + dB[4] + dB[5];
             wsum[x * 3 + 2] = ddB[3] + ddB[4] + ddB[5];
         }
+    }
+    if (t.nfixed > 0) {
+        // constrained initial state: the kernels see basis tables of the FREE coefficients only (width t.K), followed by the
+        // pinned rows' contribution per (sample, derivative, joint): q0 B_0 + (q0 + q_d0 T / 5.0) B_1   (BezierCurves.cpp:84-96,
+        // 5.0 as written there, whatever the degree)
+        const int Kz = t.K, off = t.nfixed, Nact = d->Nact;
+        std::vector<double> packed((size_t)N * 3 * Kz + (size_t)N * 3 * Nact, 0.0);
+        for (int x = 0; x < N; x++)
+            for (int dd = 0; dd < 3; dd++) {
+                const double* Bd = &basis[(size_t)(x * 3 + dd) * K];
+                for (int k = 0; k < Kz; k++) packed[(size_t)(x * 3 + dd) * Kz + k] = Bd[off + k];
+                double* fx = &packed[(size_t)N * 3 * Kz + (size_t)(x * 3 + dd) * Nact];
+                for (int j = 0; j < Nact; j++) {
+                    double v = d->q0[j] * Bd[0];
+                    if (off == 2) v += (d->q0[j] + d->q_d0[j] * T / 5.0) * Bd[1];
+                    fx[j] = v;
+                }
+            }
+        basis.swap(packed);
     }
 }
 
@@ -643,7 +669,7 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     fill_traj(S.traj, p->htraj, p->tspan, basis, wsum);
     if (S.extra_variables < 0) throw std::invalid_argument("extra_variables < 0");
     p->htraj.varLength += S.extra_variables;  // TalosSingleStepOptimizer.cpp:50-51, DigitSingleStepOptimizer.cpp:50-51
-    const int N = p->htraj.N, ni = (int)S.ind.size(), nd = (int)S.dep.size(), K = p->htraj.degree + 1;
+    const int N = p->htraj.N, ni = (int)S.ind.size(), nd = (int)S.dep.size(), K = p->htraj.K;
     if (ni != p->htraj.Nact || nd + ni != nv)
         throw std::invalid_argument("Trajectory and DynamicsConstraints must have the same number of actuated joints");
     if (!S.tl || !S.tu || !S.jl || !S.ju) throw std::invalid_argument("null array");

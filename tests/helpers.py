@@ -47,7 +47,8 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
-def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False):
+def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False,
+                   q0=None, q_d0=None):
     """Talos / Unitree-G1 single-step problem (TalosSingleStepOptimizer.cpp:17-124, G1 twin)."""
     import os
 
@@ -70,11 +71,11 @@ def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, 
         cfg.period = (robots.talos_period if which == "talos" else robots.g1_period)(m, stance)
     mh = api.model_create(m)
     keep.append(mh)
-    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV, q0=q0, q_d0=q_d0)
     return A.ProblemHandle.legged(api, mh, t, cfg), m, cfg
 
 
-def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False):
+def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customized=False, periodic=False, q0=None, q_d0=None):
     """Digit-v3 single-step problem (DigitSingleStepOptimizer.cpp:17-124)."""
     import os
 
@@ -93,5 +94,5 @@ def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customiz
         cfg.period = {}
     mh = api.model_create(m)
     keep.append(mh)
-    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV)
+    t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV, q0=q0, q_d0=q_d0)
     return A.ProblemHandle.digit(api, mh, t, cfg), m, cfg

@@ -54,6 +54,25 @@ def test_inverse_dynamics_like_reference_test(oracle, hip, kinova_friction, ttyp
     check(th2, to)
 
 
+def test_inverse_dynamics_bezier_constrained_start(oracle, hip, kinova_friction):
+    """Generic inverse-dynamics kernel on BezierCurves with constrainInitialPosition / Velocity (BezierCurves.cpp:39-69)."""
+    rng = np.random.default_rng(5)
+    q0, qd0 = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    for kw, free in ((dict(q0=q0), 5), (dict(q0=q0, q_d0=qd0), 4)):
+        po, ph, keep = both(oracle, hip, lambda api, k: H.id_problem(api, kinova_friction, k, ttype=A.TRAJ_BEZIER, degree=5,
+                                                                     disc=A.TIME_UNIFORM, **kw))
+        assert po.n == ph.n == 7 * free
+        Z = rng.uniform(-1, 1, (3, po.n))
+        to, pto = po.inverse_dynamics_host(Z, 10, 7)
+        th, pth = ph.inverse_dynamics_host(Z, 10, 7)
+        check(th, to)
+        check(pth, pto)
+        qo = po.trajectory_host(Z, 10, 7)
+        qh = ph.trajectory_host(Z, 10, 7)
+        for a, b in zip(qh, qo):
+            check(a, b, 1e-12)
+
+
 def test_inverse_dynamics_armour(oracle, hip, kinova_friction):
     rng = np.random.default_rng(2)
     q0, qd0, qdd0 = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
@@ -510,6 +529,41 @@ def test_reset_map_block(oracle, hip, robot, stance, customized):
     if robot == "digit" and customized:
         p14, _, _ = H.digit_problem(hip, keep, N=14, customized=True, periodic=True)
         assert p14.m == 1005  # 168 + 504 + 98 + 144 + 91
+
+
+@pytest.mark.parametrize("robot,vel", [("talos", False), ("g1", True), ("digit", True), ("digit", False)])
+def test_constrained_initial_state(oracle, hip, robot, vel):
+    """BezierCurves::constrainInitialPosition / constrainInitialVelocity (BezierCurves.cpp:39-69,84-96,148-162) as the
+    single-step optimizers use them when q0_input / q_d0_input are given: Nact (2 Nact) fewer variables, every block on."""
+    rng = np.random.default_rng(31)
+    q0 = 0.1 * rng.uniform(-1, 1, 12)
+    kw = dict(q0=q0, q_d0=0.2 * rng.uniform(-1, 1, 12)) if vel else dict(q0=q0)
+    keep = []
+    N = 5
+    if robot == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=N, customized=True, periodic=True, **kw)
+        ph, _, _ = H.digit_problem(hip, keep, N=N, customized=True, periodic=True, **kw)
+    else:
+        po, m, cfg = H.legged_problem(oracle, robot, keep, N=N, customized=True, periodic=True, **kw)
+        ph, _, _ = H.legged_problem(hip, robot, keep, N=N, customized=True, periodic=True, **kw)
+    free = cfg.degree + 1 - (2 if vel else 1)
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    assert po.n == 12 * free + m.nv + len(cfg.dependent_ids)
+    Z = 0.1 * rng.uniform(-1, 1, (3, po.n))
+    qo = po.trajectory_host(Z, N, 12)
+    qh = ph.trajectory_host(Z, N, 12)
+    for a, b in zip(qh, qo):
+        check(a, b, 1e-12)
+    assert np.abs(qo[0][:, 0] - q0).max() < 1e-15
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    kinds = [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_TORQUE, A.COST_MINIMIZE_INITIAL_VELOCITY, A.COST_MINIMIZE_INITIAL_ACCELERATION]
+    Fo, Do = po.costs_host(Z, kinds)
+    Fh, Dh = ph.costs_host(Z, kinds)
+    check(Fh, Fo)
+    check(Dh, Do)
 
 
 def test_legged_ragged_and_degenerate_sizes(oracle, hip):

@@ -212,3 +212,34 @@ def test_independent_formulation_reset_map(oracle, robot):
 
     eg, ej = proto_period.run(robot, N=3)
     assert eg < 1e-11 and ej < 1e-10
+
+
+def test_bezier_constrained_initial_state(oracle, kinova):
+    """BezierCurves::constrainInitialPosition / constrainInitialVelocity (BezierCurves.cpp:39-69, 84-96, 148-162): q(0) = q0,
+    q_d(0) = q_d0 at degree 5 (the T / 5.0 of :86 is the degree-5 end-point rule; at other degrees it scales, as in the
+    reference), Nact fewer variables each, pq_pz by central differences, and the ordering rule (position first)."""
+    from raptor_amd import _capi as A
+
+    rng = np.random.default_rng(9)
+    q0, qd0 = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    keep = []
+    p1 = H.id_problem(oracle, kinova, keep, ttype=A.TRAJ_BEZIER, degree=5, disc=A.TIME_UNIFORM, q0=q0)
+    p2 = H.id_problem(oracle, kinova, keep, ttype=A.TRAJ_BEZIER, degree=5, disc=A.TIME_UNIFORM, q0=q0, q_d0=qd0)
+    p3 = H.id_problem(oracle, kinova, keep, ttype=A.TRAJ_BEZIER, degree=6, disc=A.TIME_UNIFORM, q0=q0, q_d0=qd0)
+    assert (p1.n, p2.n, p3.n) == (35, 28, 35)
+    for p, deg in ((p1, 5), (p2, 5), (p3, 6)):
+        Z = rng.uniform(-1, 1, (1, p.n))
+        q, qd, qdd = p.trajectory_host(Z, 10, 7)
+        assert np.abs(q[0, 0] - q0).max() < 1e-15
+        if p is not p1:
+            assert np.abs(qd[0, 0] - qd0 * deg / 5.0).max() < 1e-13
+        h = 1e-6
+        tau, ptau = p.inverse_dynamics_host(Z, 10, 7)
+        for c in range(0, p.n, 3):
+            zp, zm = Z.copy(), Z.copy()
+            zp[0, c] += h
+            zm[0, c] -= h
+            fd = (p.inverse_dynamics_host(zp, 10, 7, derivatives=False)[0] - p.inverse_dynamics_host(zm, 10, 7, derivatives=False)[0]) / (2 * h)
+            assert np.abs(fd[0] - ptau[0, :, :, c]).max() < 1e-5 * (1 + np.abs(ptau[0, :, :, c]).max())
+    with pytest.raises(A.RaptorInvalidArgument):  # "initial position must be constrained first"
+        H.id_problem(oracle, kinova, keep, ttype=A.TRAJ_BEZIER, degree=5, q_d0=qd0)
