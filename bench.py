@@ -73,7 +73,7 @@ class Legged:
         self.workload = (f"{'Talos' if which == 'talos' else 'Unitree-G1'} single-step gait, nv=18 (6 floating + 12), Bezier degree 6, "
                          f"14 Chebyshev samples x {self.batch} random z in 0.1*U(-1,1)^108 per GPU, eval_g+eval_jac_g "
                          "(torque limits + constrained joint limits + rectangle contact + customized swing-foot / torso rows + reset map: "
-                         "all 583 rows of the reference's single-step problem), no solver")
+                         "all 729 rows of the reference's single-step problem), no solver")
 
     def build(self, api, keep):
         import helpers as H

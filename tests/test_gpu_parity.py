@@ -325,7 +325,8 @@ def test_legged_full_size_properties(hip):
     import torch
 
     keep = []
-    p, m, cfg = H.legged_problem(hip, "g1", keep, N=14)
+    p, m, cfg = H.legged_problem(hip, "g1", keep, N=14, customized=True, periodic=True)  # all 729 rows of the reference's problem
+    assert p.m == 729
     B = 1024
     g = torch.Generator(device="cpu").manual_seed(20250527)
     Z = (0.1 * (torch.rand(B, p.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
@@ -410,7 +411,8 @@ def test_digit_full_size_properties(hip):
     import torch
 
     keep = []
-    p, m, cfg = H.digit_problem(hip, keep, N=14)
+    p, m, cfg = H.digit_problem(hip, keep, N=14, customized=True, periodic=True)  # all 1005 rows of the reference's problem
+    assert p.m == 1005
     B = 1024
     g = torch.Generator(device="cpu").manual_seed(20250528)
     Z = (0.1 * (torch.rand(B, p.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
