@@ -275,6 +275,19 @@ int raptor_capsule_distance_batch_host(const double* P, const double* dP, const 
                                        int n_pairs, int F, double* dist, double* grad);
 
 /*
+ * Arm-arm collision rows of DualKinovaOptimizer::eval_g / eval_jac_g
+ * (Examples/Kinova/CollisionAvoidanceTrajectory/src/DualKinovaOptimizer.cpp:269-305, 449-510): for two Kinova problems with
+ * the same N, per sample the four pairs (tapered capsule 1, 2 of robot 1) x (tapered capsule 1, 2 of robot 2), each capsule
+ * spanned by two collision spheres (KinovaCustomizedConstraints.h:58-63; the gripper extends the last capsule).
+ *   Z [B][numVars1 + numVars2] (robot 1's variables first) -> G [B][N*4], JAC [B][N*4][numVars1 + numVars2] row-major.
+ * The two robots' own blocks come from raptor_eval_batch on each problem, as the reference calls the two KinovaOptimizers.
+ */
+int raptor_dual_kinova_arm_arm_batch(raptor_problem* problem1, raptor_problem* problem2, const double* d_Z, int B,
+                                     unsigned flags, double* d_G, double* d_JAC, void* hip_stream);
+int raptor_dual_kinova_arm_arm_batch_host(raptor_problem* problem1, raptor_problem* problem2, const double* Z, int B,
+                                          unsigned flags, double* G, double* JAC);
+
+/*
  * Per-kernel timing with HIP events recorded on the evaluation stream, for measurement harnesses
  * (the reference keeps per-callback wall-clock counters instead: Optimization/src/Optimizer.cpp:717-754).
  * Between _begin and _end every raptor_eval_batch records events around its kernel launches, up to

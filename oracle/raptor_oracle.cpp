@@ -937,6 +937,7 @@ struct KinovaCustomizedConstraints : Constraints {
     std::vector<int> sphere_joint_id;
     std::vector<Vec3> sphere_offset;
     std::vector<double> sphere_radius;
+    std::vector<std::pair<int, int>> tapered_capsules;  // KinovaCustomizedConstraints.h:58-63
     KinovaCustomizedConstraints(Trajectory* t, const Model* mdl, int O, const double* bc, const double* brpy,
                                 const double* bs, bool include_gripper, double buffer)
         : traj(t), model(mdl), collision_buffer(buffer) {
@@ -948,6 +949,8 @@ struct KinovaCustomizedConstraints : Constraints {
             sphere_offset.push_back(Vec3(SPHERE_OFFSET[i][0], SPHERE_OFFSET[i][1], SPHERE_OFFSET[i][2]));
             sphere_radius.push_back(SPHERE_RADIUS[i]);
         }
+        tapered_capsules = {{0, 6}, {7, 11}, {12, 13}};  // :36-39
+        if (include_gripper) tapered_capsules.back().second = 19;  // :46
         if (include_gripper) {  // :42-47
             const double zs[3] = {-0.10, -0.15, -0.20};
             for (int k = 0; k < 3; k++) {
@@ -986,6 +989,13 @@ struct KinovaCustomizedConstraints : Constraints {
     void compute_bounds() override {  // :160-164
         std::fill(g_lb.begin(), g_lb.end(), collision_buffer);
         std::fill(g_ub.begin(), g_ub.end(), 1e19);
+    }
+    // sphere_centers_copy(j, i) and sphere_centers_gradient_copy(j, i) (:109, :114) for a trajectory already computed
+    void sphere_center(int i, int j, bool d, Vec3& c, MatX& pc) {
+        Transform endT(sphere_offset[j]);
+        fk.compute(0, sphere_joint_id[j], traj->q[i].data(), nullptr, &endT, d ? 1 : 0);
+        c = fk.getTranslation();
+        if (d) pc = fk.getTranslationJacobian() * traj->pq_pz[i];
     }
 };
 
@@ -1721,6 +1731,60 @@ int oracle_capsule_distance_batch_host(const double* P, const double* dP, const 
 int oracle_capsule_distance_batch(const double* P, const double* dP, const double* R, int n_pairs, int F, double* dist,
                                   double* grad, void*) {
     return oracle_capsule_distance_batch_host(P, dP, R, n_pairs, F, dist, grad);
+}
+
+// Arm-arm rows of DualKinovaOptimizer::eval_g / eval_jac_g
+// (Examples/Kinova/CollisionAvoidanceTrajectory/src/DualKinovaOptimizer.cpp:269-305, 449-510)
+int oracle_dual_kinova_arm_arm_batch_host(raptor_problem* pr1, raptor_problem* pr2, const double* Z, int B, unsigned flags,
+                                          double* G, double* JAC);
+int oracle_dual_kinova_arm_arm_batch(raptor_problem* pr1, raptor_problem* pr2, const double* Z, int B, unsigned flags, double* G,
+                                     double* JAC, void*) {
+    return oracle_dual_kinova_arm_arm_batch_host(pr1, pr2, Z, B, flags, G, JAC);
+}
+int oracle_dual_kinova_arm_arm_batch_host(raptor_problem* pr1, raptor_problem* pr2, const double* Z, int B, unsigned flags,
+                                          double* G, double* JAC) {
+    ORACLE_TRY
+    if (!pr1 || !pr2 || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    Problem &p1 = pr1->p, &p2 = pr2->p;
+    KinovaCustomizedConstraints* k1 = p1.cons.empty() ? nullptr : dynamic_cast<KinovaCustomizedConstraints*>(p1.cons.back().get());
+    KinovaCustomizedConstraints* k2 = p2.cons.empty() ? nullptr : dynamic_cast<KinovaCustomizedConstraints*>(p2.cons.back().get());
+    if (!k1 || !k2) throw std::invalid_argument("dual Kinova: both problems must end with KinovaCustomizedConstraints");
+    if (p1.traj.N != p2.traj.N) throw std::invalid_argument("dual Kinova: the two trajectories must have the same N");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && !JAC) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && !G) throw std::invalid_argument("G buffer is null");
+    const int N = p1.traj.N, n1 = p1.traj.varLength, n2 = p2.traj.varLength, nvars = n1 + n2, rows = N * 4;
+    for (int b = 0; b < B; b++) {
+        const double* z = Z + (size_t)b * nvars;
+        p1.traj.compute(z, jac);
+        p2.traj.compute(z + n1, jac);
+        for (int i = 0; i < N; i++) {
+            int j = 0;
+            for (int j1 = 1; j1 < 3; j1++)
+                for (int j2 = 1; j2 < 3; j2++) {
+                    const int ids[4] = {k1->tapered_capsules[j1].first, k1->tapered_capsules[j1].second,
+                                        k2->tapered_capsules[j2].first, k2->tapered_capsules[j2].second};
+                    double P[12], R[4];
+                    std::vector<double> dP(jac ? (size_t)12 * nvars : 0, 0.0);  // dk_tc*_sphere_*: zero outside the own robot's columns
+                    for (int e = 0; e < 4; e++) {
+                        KinovaCustomizedConstraints* k = e < 2 ? k1 : k2;
+                        Vec3 c;
+                        MatX pc;
+                        k->sphere_center(i, ids[e], jac, c, pc);
+                        for (int x = 0; x < 3; x++) P[e * 3 + x] = c(x);
+                        R[e] = k->sphere_radius[ids[e]];
+                        if (jac)
+                            for (int x = 0; x < 3; x++)
+                                for (int cc = 0; cc < (e < 2 ? n1 : n2); cc++) dP[(size_t)(e * 3 + x) * nvars + (e < 2 ? 0 : n1) + cc] = pc(x, cc);
+                    }
+                    const size_t row = (size_t)b * rows + i * 4 + j;
+                    const double dist = capsule_distance(P, jac ? dP.data() : nullptr, R, nvars, jac ? JAC + row * nvars : nullptr);
+                    if (flags & RAPTOR_EVAL_G) G[row] = dist;
+                    j++;
+                }
+        }
+    }
+    ORACLE_CATCH
 }
 
 int oracle_init(int) { return RAPTOR_OK; }

@@ -221,6 +221,7 @@ EXPORTS = [
     "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
+    "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host",
 ]
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
 DEVICE_ONLY_EXPORTS = ["probe_fill"]
@@ -258,6 +259,8 @@ class CApi:
         f("digit_problem_create").argtypes = [vp, C.POINTER(DigitDesc), C.POINTER(vp)]
         f("eval_costs").argtypes = [vp, vp, C.c_int, C.c_int, _ip, vp, vp, vp]
         f("eval_costs_host").argtypes = [vp, _dp, C.c_int, C.c_int, _ip, _dp, _dp]
+        f("dual_kinova_arm_arm_batch").argtypes = [vp, vp, vp, C.c_int, C.c_uint, vp, vp, vp]
+        f("dual_kinova_arm_arm_batch_host").argtypes = [vp, vp, _dp, C.c_int, C.c_uint, _dp, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         if prefix == "raptor_":
@@ -282,6 +285,17 @@ class CApi:
     # -- model ---------------------------------------------------------------------------
     def model_create(self, model) -> "ModelHandle":
         return ModelHandle(self, model)
+
+    def dual_kinova_arm_arm_host(self, p1: "ProblemHandle", p2: "ProblemHandle", Z, N: int, flags: int = EVAL_G | EVAL_JAC):
+        """Arm-arm rows of DualKinovaOptimizer: Z [B][n1 + n2] -> g [B][N*4], jac [B][N*4][n1 + n2] (None if not asked for)."""
+        nvars = p1.n + p2.n
+        Z = _f64(Z).reshape(-1, nvars)
+        B = Z.shape[0]
+        rows = N * 4
+        G = np.empty((B, rows)) if flags & EVAL_G else None
+        J = np.empty((B, rows, nvars)) if flags & EVAL_JAC else None
+        self.check(self._f("dual_kinova_arm_arm_batch_host")(p1.handle, p2.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J)))
+        return G, J
 
     def capsule_distance_host(self, P, dP, R):
         P = _f64(P).reshape(-1, 4, 3)

@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "capsule_kernel.h"
+#include "dual_kernel.h"
 #include "kinova_kernel.h"
 #include "legged_kernel.h"
 #include "digit_kernel.h"
@@ -1425,6 +1426,73 @@ int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const d
     hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(n_pairs)), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_P, d_dP,
                        d_R, n_pairs, F, d_dist, d_grad);
     HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+// DualKinovaOptimizer.cpp:269-305, 449-510
+static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const double* dZ, int B, unsigned flags, double* dG,
+                                double* dJ, hipStream_t st) {
+    if (p1.kind != 1 || p2.kind != 1) throw std::invalid_argument("dual Kinova: both problems must be Kinova problems");
+    if (p1.htraj.N != p2.htraj.N) throw std::invalid_argument("dual Kinova: the two trajectories must have the same N");
+    if (!(flags & (RAPTOR_EVAL_G | RAPTOR_EVAL_JAC))) throw std::invalid_argument("flags: nothing to evaluate");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && dJ == nullptr) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && dG == nullptr) throw std::invalid_argument("G buffer is null");
+    if (B < 0) throw std::invalid_argument("negative batch size");
+    if (B == 0) return;
+    if (dZ == nullptr) throw std::invalid_argument("Z is null");
+    DualCapsules caps;
+    raptor_problem* pr[2] = {&p1, &p2};
+    for (int r = 0; r < 2; r++) {  // TAPERED_CAPSULES[1], [2] (KinovaCustomizedConstraints.h:58-63); the gripper extends the last one (.cpp:46)
+        if (pr[r]->hspheres.num_spheres < 17) throw std::invalid_argument("dual Kinova: the sphere table has no tapered capsules");
+        caps.ids[r][0][0] = 7;  caps.ids[r][0][1] = 11;
+        caps.ids[r][1][0] = 12; caps.ids[r][1][1] = pr[r]->hspheres.num_spheres >= 20 ? 19 : 13;
+    }
+    const long long total = (long long)B * p1.htraj.N * 4;
+    const int CH = 32768;  // pairs per pass: bounds the staging area (12 + 168 + 4 doubles per pair)
+    p1.s_a.ensure((size_t)CH * 12);
+    if (jac) p1.s_b.ensure((size_t)CH * 12 * 14);
+    p1.s_c.ensure((size_t)CH * 5);
+    double* dR = p1.s_c.p;
+    double* dDist = p1.s_c.p + (size_t)CH * 4;
+    for (long long p0 = 0; p0 < total; p0 += CH) {
+        const int np = (int)std::min<long long>(CH, total - p0);
+        hipLaunchKernelGGL(dual_kinova_points_kernel, dim3((np + 63) / 64), dim3(64), 0, st, p1.d_model.p, p1.d_traj.p, p1.d_basis.p,
+                           p1.d_wsum.p, p1.d_spheres.p, p2.d_model.p, p2.d_traj.p, p2.d_basis.p, p2.d_wsum.p, p2.d_spheres.p, caps, dZ,
+                           p0, np, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR);
+        hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(np)), dim3(RAPTOR_BLOCK), 0, st, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR, np, 14,
+                           (flags & RAPTOR_EVAL_G) ? dG + p0 : dDist, jac ? dJ + (size_t)p0 * 14 : nullptr);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+int raptor_dual_kinova_arm_arm_batch(raptor_problem* p1, raptor_problem* p2, const double* d_Z, int B, unsigned flags,
+                                     double* d_G, double* d_JAC, void* stream) {
+    API_TRY
+    if (!p1 || !p2) throw std::invalid_argument("null argument");
+    dual_arm_arm_device(*p1, *p2, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    API_CATCH
+}
+
+int raptor_dual_kinova_arm_arm_batch_host(raptor_problem* p1, raptor_problem* p2, const double* Z, int B, unsigned flags,
+                                          double* G, double* JAC) {
+    API_TRY
+    if (!p1 || !p2) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("negative batch size");
+    if (B > 0 && !Z) throw std::invalid_argument("Z is null");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && !JAC) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && !G) throw std::invalid_argument("G buffer is null");
+    if (B == 0) return RAPTOR_OK;
+    const size_t rows = (size_t)p1->htraj.N * 4;
+    p1->s_Z.ensure((size_t)B * 14);
+    p1->s_G.ensure((size_t)B * rows);
+    if (jac) p1->s_J.ensure((size_t)B * rows * 14);
+    HIP_CHECK(hipMemcpy(p1->s_Z.p, Z, (size_t)B * 14 * sizeof(double), hipMemcpyHostToDevice));
+    dual_arm_arm_device(*p1, *p2, p1->s_Z.p, B, flags, p1->s_G.p, jac ? p1->s_J.p : nullptr, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (flags & RAPTOR_EVAL_G) HIP_CHECK(hipMemcpy(G, p1->s_G.p, (size_t)B * rows * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac) HIP_CHECK(hipMemcpy(JAC, p1->s_J.p, (size_t)B * rows * 14 * sizeof(double), hipMemcpyDeviceToHost));
     API_CATCH
 }
 

@@ -180,6 +180,29 @@ def test_capsule_known_answers_and_random(oracle, hip):
         assert np.quantile(err, 0.999) < 1e-7, np.quantile(err, 0.999)
 
 
+def test_dual_kinova_arm_arm_rows(oracle, hip, kinova):
+    """DualKinovaOptimizer arm-arm rows (DualKinovaOptimizer.cpp:269-305, 449-510): N*4 capsule rows x 14 columns, with and
+    without the gripper capsule, G-only and full evaluation, a batch that spans several staging passes."""
+    m2 = kinova.copy()
+    m2.placement_p = m2.placement_p.copy()
+    m2.placement_p[0] = m2.placement_p[0] + np.array([0.55, 0.25, 0.0])
+    rng = np.random.default_rng(23)
+    for N, B, grip in ((7, 5, False), (16, 600, True)):  # 600 * 16 * 4 = 38400 pairs > one 32768-pair pass
+        keep = []
+        o1, o2 = H.kinova_problem(oracle, kinova, keep, N=N), H.kinova_problem(oracle, m2, keep, N=N, gripper=grip)
+        h1, h2 = H.kinova_problem(hip, kinova, keep, N=N), H.kinova_problem(hip, m2, keep, N=N, gripper=grip)
+        Z = rng.uniform(-1, 1, (B, 14))
+        Go, Jo = oracle.dual_kinova_arm_arm_host(o1, o2, Z, N)
+        Gh, Jh = hip.dual_kinova_arm_arm_host(h1, h2, Z, N)
+        check(Gh, Go)
+        check(Jh, Jo)
+        Gh2, none = hip.dual_kinova_arm_arm_host(h1, h2, Z, N, A.EVAL_G)
+        assert none is None
+        check(Gh2, Gh, 1e-13)
+    with pytest.raises(A.RaptorInvalidArgument):
+        hip.dual_kinova_arm_arm_host(h1, H.kinova_problem(hip, m2, keep, N=3), Z, N)
+
+
 def test_full_size_properties(hip, kinova):
     """BASELINE config 2 size (N = 128, B = 4096) through the device-pointer entry point: properties that
     need no oracle -- batch-order equivariance, eval_g/eval_jac_g consistency, finite outputs."""

@@ -311,3 +311,38 @@ def test_error_codes(oracle, kinova):
     bad.parent[2] = 5
     with pytest.raises(A.RaptorInvalidArgument):
         oracle.model_create(bad)
+
+
+def test_dual_kinova_arm_arm_rows(oracle, kinova):
+    """DualKinovaOptimizer.cpp:269-305, 449-510: N*4 tapered-capsule rows between two arms, 14 columns.  Pins: the sphere centres
+    are where an independent numpy FK puts them (through the capsule routine on those points), the gradient by central
+    differences (the reference checks its constraint gradients the same way), zero blocks outside the own robot's columns."""
+    import helpers as H
+    from raptor_amd import _capi as A
+
+    keep = []
+    m2 = kinova.copy()
+    m2.placement_p = m2.placement_p.copy()
+    m2.placement_p[0] = m2.placement_p[0] + np.array([0.55, 0.25, 0.0])
+    N = 6
+    p1 = H.kinova_problem(oracle, kinova, keep, N=N)
+    p2 = H.kinova_problem(oracle, m2, keep, N=N, gripper=True)
+    rng = np.random.default_rng(17)
+    Z = rng.uniform(-1, 1, (2, 14))
+    G, J = oracle.dual_kinova_arm_arm_host(p1, p2, Z, N)
+    assert G.shape == (2, N * 4) and J.shape == (2, N * 4, 14)
+    h = 1e-6
+    for c in range(14):
+        zp, zm = Z.copy(), Z.copy()
+        zp[:, c] += h
+        zm[:, c] -= h
+        fd = (oracle.dual_kinova_arm_arm_host(p1, p2, zp, N, A.EVAL_G)[0] - oracle.dual_kinova_arm_arm_host(p1, p2, zm, N, A.EVAL_G)[0]) / (2 * h)
+        assert np.abs(fd - J[:, :, c]).max() < 1e-5, c
+    # same z for both arms, second arm shifted: the distance of like capsules is bounded by the base offset
+    Zs = np.concatenate([Z[:, :7], Z[:, :7]], axis=1)
+    p2b = H.kinova_problem(oracle, m2, keep, N=N)
+    Gs, _ = oracle.dual_kinova_arm_arm_host(p1, p2b, Zs, N, A.EVAL_G)
+    off = np.linalg.norm([0.55, 0.25, 0.0])
+    assert np.all(Gs.reshape(2, N, 4)[:, :, [0, 3]] <= off + 1e-12)
+    with pytest.raises(A.RaptorInvalidArgument):
+        oracle.dual_kinova_arm_arm_host(p1, H.kinova_problem(oracle, m2, keep, N=N + 1), Z, N)
