@@ -36,3 +36,32 @@ def test_argument_errors_without_gpu():
     out = ctypes.c_void_p()
     assert api.fn("model_create")(None, ctypes.byref(out)) == _capi.ERR_INVALID_ARGUMENT
     assert b"null" in api.fn("last_error")()
+
+
+def test_reset_map_wiring_errors_without_gpu(oracle):
+    """The reset-map block needs v_reset / lambda_reset in z and a complete JOINT_MAP: refused the same way by the oracle and by the
+    HIP library's host-side validation (no GPU needed: set-up checks run before the first HIP call)."""
+    import os
+
+    import pytest
+
+    import helpers as H
+    from raptor_amd import robots
+
+    rd = os.path.join(ROOT, "tests", "robots")
+    m = robots.talos_model(os.path.join(rd, "talos_reduced_armfixed_floatingbase.urdf"))
+    for api in (oracle, raptor_amd.api()):
+        keep = []
+        mh = api.model_create(m)
+        keep.append(mh)
+        cfg = robots.talos_config(m)
+        cfg.period = robots.talos_period(m)
+        cfg.extra_variables = 0
+        t = _capi.make_traj_desc(keep, _capi.TRAJ_BEZIER, cfg.T, 4, 12, cfg.degree, _capi.TIME_CHEBYSHEV)
+        with pytest.raises(_capi.RaptorInvalidArgument):
+            _capi.ProblemHandle.legged(api, mh, t, cfg)
+        cfg = robots.talos_config(m)
+        cfg.period = dict(robots.talos_period(m))
+        del cfg.period["joint_id1"], cfg.period["joint_id2"]
+        with pytest.raises(_capi.RaptorInvalidArgument):
+            _capi.ProblemHandle.legged(api, mh, t, cfg)
