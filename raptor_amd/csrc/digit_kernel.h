@@ -42,7 +42,6 @@ struct DevLoop {
 };
 struct DevDigit {
     DevLoop loop[2][2];  // [leg][0: knee, 1: toe]
-    int pair_idx[16][2];
     int recs_per_sample;  // 18
 };
 

@@ -7,13 +7,14 @@
 // MI355X design -- NOT the reference's algorithm order.  The reference forms crba(q-), J, the tensors Jx_partial_dq and
 // JTx_partial_dq, a gravity-free computeRNEADerivatives and multiplies by pq_pz(last), pv_pz(last) (nv x varLength).
 // Only 12 directions matter: along actuator t the robot moves on the stance-phase manifold with joint rates
-// u = Pfull[:, t] (already in the core kernel's record).  With w_l the world-frame twist of body l per unit q_t,
-//     D_t s_k = w_k x s_k      D_t (I_l a) = w_l x* (I_l a) - I_l (w_l x a) + I_l D_t a      D_t p_c = w_foot at p_c
-// so every term of D_t g1, D_t g2 is a path walk plus a subtree sum, and d v-/d q_t needs no J_dep^-1: the planted foot
-// stays planted, sum_base s_b Vq_b = -(sum over the old stance foot's path of (w_j x s_j) v-_j + s_j Vq_j).
-// One wavefront per decision vector, lane = joint of the model's own tree in DFS pre-order (subtree = lane range,
-// composites by wave shuffles); the block's rows are assembled in LDS pieces and streamed out densely.
-// numpy model: scripts/proto_period.py (agrees with the oracle's literal restatement to 5e-14).
+// Pfull[:, t] (identity rows + the P_dep already in the core kernel's record), so
+//     pg1 = (A Pfull - H Vq) B_k(T) - (H Pfull) dB_k(T),     A = d(H dv - J^T lambda)/dq,  Vq = d v-/d q_t.
+// A comes from per-joint 6-vectors in world-frame algebra (psi_k = a_parent x s_k, IS_k = I^C_k s_k, the contact wrench W of
+// lambda.tail(6) and X_k = s_k x* W - d_k W, cq_k = s_k x* F_k + I^C_k psi_k + X_k), no tensors; Vq needs no J_dep^-1: the old
+// stance foot stays planted, sum_base s_b Vq_b = -(sum over its path of (w_j x s_j) v-_j + s_j Vq_j), a 3 x 3 solve.
+// One workgroup of four wavefronts per decision vector: wavefront 0 walks the model's own tree (lane = joint in DFS pre-order,
+// composites by wave shuffles), wavefront 1 builds Pfull and Vq meanwhile, then all do the small products and stream the rows
+// out densely.  numpy models: scripts/proto_period.py (directional and matrix forms, both agree with the oracle to 5e-14).
 #ifndef RAPTOR_PERIOD_KERNEL_H
 #define RAPTOR_PERIOD_KERNEL_H
 

@@ -1084,10 +1084,6 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
     std::unique_ptr<DevDigit> D(new DevDigit());
     std::memset(D.get(), 0, sizeof(DevDigit));
     D->recs_per_sample = 18;
-    for (int k = 0; k < 16; k++) {
-        D->pair_idx[k][0] = DIGIT_TOE_PAIR[k][0];
-        D->pair_idx[k][1] = DIGIT_TOE_PAIR[k][1];
-    }
     S.loop_rec.assign(nv, -1);
     S.loop_drv_a.assign(nv, -1);
     S.loop_drv_b.assign(nv, -1);
