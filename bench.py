@@ -117,6 +117,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Digit record appended to the default (Kinova) line")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loop (profiling runs: keeps the kernel statistics to the batch launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -233,15 +234,16 @@ def main() -> None:
             "kernels_ms": {k: v for k, v in zip(W.kernels, kms) if k},
         }
         # single-problem latency (the Ipopt-driven use: one z, eval_g + eval_jac_g, results left in HBM), host-synchronised per call
-        for _ in range(5):
-            prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
-        torch.cuda.synchronize()
-        reps = 200
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
+        if not args.no_latency:
+            for _ in range(5):
+                prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
             torch.cuda.synchronize()
-        out["single_problem_eval_jac_g_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
+            reps = 200
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
+                torch.cuda.synchronize()
+            out["single_problem_eval_jac_g_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
         if world == 1 and cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), cpu_seconds, G, J)
         return out

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="$R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
+ARGS="$R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-latency"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $ARGS > $OUT/w.json 2> $OUT/w.err || exit 1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ARGS > $OUT/f.json 2> $OUT/f.err || exit 1
