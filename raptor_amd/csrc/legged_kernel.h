@@ -576,20 +576,22 @@ RD void store2_stream(double* p, double a, double b) {
 }
 
 template <int PIECE>
-RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, double* __restrict__ dst,
-                            const double* __restrict__ rec, const double* __restrict__ wB, const int* __restrict__ tcol,
-                            const int* __restrict__ rowinfo, const DevLegged* __restrict__ Q) {
-    const double* D = rec + Q->c_D;
-    const double* Lm = rec + Q->c_L;
-    const double* Pb = rec + Q->c_P;
-    const double* Pl = rec + Q->c_Pl;
-    const double* lam = rec + Q->c_lam;
+RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, const int cnt,
+                            double* __restrict__ dst, const double* __restrict__ rec0, const int recstride,
+                            const double* __restrict__ wB0, const int* __restrict__ tcol, const int* __restrict__ rowinfo,
+                            const DevLegged* __restrict__ Q) {
+    // `cnt` (1 or 2) consecutive samples of one decision vector: their rows of a block are adjacent, so the piece is one
+    // contiguous run of cnt * R rows
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
     const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
-    const int total = R * n;
+    const int total = cnt * R * n;
     int el = 2 * tid;
     int r = el / n, c = el - r * n;
     for (; el < total; el += 2 * LEG_EXP_BLOCK) {
+        const int sidx = (r >= R) ? 1 : 0;
+        const int rr_ = r - sidx * R;
+        const double* rec = rec0 + sidx * recstride;
+        const double* wB = wB0 + sidx * 3 * ndyn;
         double o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -599,10 +601,12 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
                 const int t = tcol[cc];
                 const double B0 = wB[cc];
                 if (PIECE == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
-                    const double* d = D + (t * 3) * ni + r;
+                    const double* d = rec + Q->c_D + (t * 3) * ni + rr_;
                     val = d[0] * B0 + d[ni] * wB[ndyn + cc] + d[2 * ni] * wB[2 * ndyn + cc];
                 } else if (PIECE == 1) {  // ConstrainedJointLimits.cpp:59-68
-                    const int info = rowinfo[r];  // >= 0: independent index; < 0: -1 - dependent index
+                    const double* Pb = rec + Q->c_P;
+                    const double* Pl = rec + Q->c_Pl;
+                    const int info = rowinfo[rr_];  // >= 0: independent index; < 0: -1 - dependent index
                     if (info >= 0) {
                         val = (info == t) ? B0 : 0.0;
                     } else {
@@ -615,10 +619,10 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
                 } else {  // RectangleSurfaceContactConstraints.cpp:52-93
                     double p[6];
                     const double B1 = wB[ndyn + cc], B2 = wB[2 * ndyn + cc];
-                    const double* l = Lm + (t * 3) * 6;
+                    const double* l = rec + Q->c_L + (t * 3) * 6;
 #pragma unroll
-                    for (int rr = 0; rr < 6; rr++) p[rr] = l[rr] * B0 + l[6 + rr] * B1 + l[12 + rr] * B2;
-                    val = contact_row(r, lam, p, mu, gam, Lx, Ly);
+                    for (int q = 0; q < 6; q++) p[q] = l[q] * B0 + l[6 + q] * B1 + l[12 + q] * B2;
+                    val = contact_row(rr_, rec + Q->c_lam, p, mu, gam, Lx, Ly);
                 }
             }
             o[h] = val;
@@ -669,30 +673,35 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
                                                                      const double* __restrict__ core,
                                                                      const DevCustRow* __restrict__ cust,
                                                                      const int* __restrict__ cust_list,
-                                                                     const int* __restrict__ cust_start,
+                                                                     const int* __restrict__ cust_start, const int spw,
                                                                      double* __restrict__ JAC) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    const long long e = blockIdx.x;
     const int N = T->N;
-    const int i = (int)(e % N);
-    const long long b = e / N;
+    const int groups = (N + spw - 1) / spw;   // workgroups per decision vector, spw (1 or 2) consecutive samples each
+    const long long b = blockIdx.x / groups;
+    const int i = (int)(blockIdx.x - b * groups) * spw;
+    const int cnt = (i + spw <= N) ? spw : N - i;
+    const long long e = b * N + i;
     const int ni = Q->ni, nv = Q->nv, nd = Q->nd, K = Q->K, n = L.n;
     const int ndyn = ni * K;
     const int stride = Q->c_stride;
-    double* rec = lds;
-    double* wB = lds + stride;                                   // [3][ndyn]
-    int* tcol = reinterpret_cast<int*>(wB + 3 * ndyn);           // [ndyn]
-    int* rowinfo = tcol + ndyn;                                  // [MAX_NV] row kind, then [MAX_NV][2] dep_col
-    const double* src = core + (size_t)e * stride;
-    for (int k = tid; k < stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
-    for (int c = tid; c < ndyn; c += LEG_EXP_BLOCK) {
-        const int t = c / K, k = c - t * K;
-        const double* Bs = basis + (size_t)(i * 3) * K + k;
-        wB[c] = Bs[0];
-        wB[ndyn + c] = Bs[K];
-        wB[2 * ndyn + c] = Bs[2 * K];
-        tcol[c] = t;
+    double* rec = lds;                                            // [spw][stride]
+    double* wB = lds + spw * stride;                              // [spw][3][ndyn]
+    int* tcol = reinterpret_cast<int*>(wB + spw * 3 * ndyn);      // [ndyn]
+    int* rowinfo = tcol + ndyn;                                   // [MAX_NV] row kind, then [MAX_NV][2] dep_col
+    const double* src = core + (size_t)e * stride;                // the records of consecutive samples are adjacent
+    for (int k = tid; k < cnt * stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
+    for (int c = tid; c < cnt * ndyn; c += LEG_EXP_BLOCK) {
+        const int sidx = (c >= ndyn) ? 1 : 0;
+        const int cc = c - sidx * ndyn;
+        const int t = cc / K, k = cc - t * K;
+        const double* Bs = basis + (size_t)((i + sidx) * 3) * K + k;
+        double* w = wB + sidx * 3 * ndyn;
+        w[cc] = Bs[0];
+        w[ndyn + cc] = Bs[K];
+        w[2 * ndyn + cc] = Bs[2 * K];
+        if (sidx == 0) tcol[cc] = t;
     }
     if (tid < nv) rowinfo[tid] = (Q->joint_ind[tid] >= 0) ? Q->joint_ind[tid] : -1 - Q->joint_dep[tid];
     if (tid < nd) {
@@ -700,14 +709,15 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
         rowinfo[RAPTOR_MAX_NV + 2 * tid + 1] = Q->dep_col[tid][1];
     }
     __syncthreads();
-    // the three row blocks of this sample are contiguous pieces of the output; 16-byte aligned because n is even
+    // the row blocks of these samples are contiguous pieces of the output; 16-byte aligned because n is even
     double* base = JAC + (size_t)b * L.m * n;
-    legged_expand_piece<0>(tid, n, ndyn, ni, ni, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, wB, tcol, rowinfo, Q);
-    legged_expand_piece<1>(tid, n, ndyn, ni, nv, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, wB, tcol, rowinfo, Q);
-    legged_expand_piece<2>(tid, n, ndyn, ni, 7, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, wB, tcol, rowinfo, Q);
+    legged_expand_piece<0>(tid, n, ndyn, ni, ni, cnt, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, stride, wB, tcol, rowinfo, Q);
+    legged_expand_piece<1>(tid, n, ndyn, ni, nv, cnt, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, stride, wB, tcol, rowinfo, Q);
+    legged_expand_piece<2>(tid, n, ndyn, ni, 7, cnt, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, stride, wB, tcol, rowinfo, Q);
     if (Q->ncust > 0)
-        legged_expand_cust(tid, n, ndyn, cust_start[i + 1] - cust_start[i], cust_list + cust_start[i], cust,
-                           base + (size_t)Q->off_cust * n, rec, wB, tcol, Q);
+        for (int sidx = 0; sidx < cnt; sidx++)
+            legged_expand_cust(tid, n, ndyn, cust_start[i + sidx + 1] - cust_start[i + sidx], cust_list + cust_start[i + sidx], cust,
+                               base + (size_t)Q->off_cust * n, rec + sidx * stride, wB + sidx * 3 * ndyn, tcol, Q);
 }
 
 // fallback for an odd number of columns: one entry per lane

@@ -409,9 +409,11 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     if (p.layout.n % 2 == 0 && ((size_t)dJ & 15) == 0) {
         if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
         const int ndyn = p.hleg.ni * p.hleg.K;
-        const size_t lds_bytes = (size_t)(p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
-        hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)E), dim3(LEG_EXP_BLOCK), lds_bytes, st, p.d_traj.p, p.d_leg.p,
-                           p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, dJ);
+        const int spw = p.htraj.N >= 2 ? 2 : 1;  // two consecutive samples per workgroup: longer contiguous pieces, half the prologues
+        const int groups = (p.htraj.N + spw - 1) / spw;
+        const size_t lds_bytes = (size_t)spw * (p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
+        hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)((long long)B * groups)), dim3(LEG_EXP_BLOCK), lds_bytes, st, p.d_traj.p,
+                           p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, spw, dJ);
     } else {
         const long long total = (long long)B * p.layout.m * p.layout.n;
         if (total / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
