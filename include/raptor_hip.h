@@ -275,6 +275,21 @@ int raptor_capsule_distance_batch_host(const double* P, const double* dP, const 
                                        int n_pairs, int F, double* dist, double* grad);
 
 /*
+ * The block that links walking step s to step s + 1 in the multiple-step optimizers:
+ * DigitMultipleStepPeriodicityConstraints::compute (Examples/Digit/src/DigitMultipleStepPeriodicityConstraints.cpp:57-230) and
+ * its Talos / Unitree-G1 twins.  `curr` is step s, created with period.enabled (its reset-map tables: stance swap, contact
+ * parameters); `next` is step s + 1 (the other stance leg; the last link of a periodic gait takes step 0).  Rows as in the
+ * single-step block except the reset rows: g3 = q_next(0)[independent] - q-[independent], g4 = v_next(0)[independent] - v+[independent].
+ *   Zcurr, Znext [B][n] -> G [B][mp], JAC = pg_pz [B][mp][n] (w.r.t. Zcurr), JAC2 = rows of pg3_pz2, pg4_pz2 [B][2 Nact][n]
+ *   (w.r.t. Znext), mp = nv + n_dep + 2 Nact + 7.  The steps' own blocks come from raptor_eval_batch on each step's problem,
+ *   as DigitMultipleStepOptimizer calls its DigitSingleStepOptimizer members (DigitMultipleStepOptimizer.cpp:36-60).
+ */
+int raptor_step_link_eval_batch(raptor_problem* curr, raptor_problem* next, const double* d_Zcurr, const double* d_Znext, int B,
+                                unsigned flags, double* d_G, double* d_JAC, double* d_JAC2, void* hip_stream);
+int raptor_step_link_eval_batch_host(raptor_problem* curr, raptor_problem* next, const double* Zcurr, const double* Znext, int B,
+                                     unsigned flags, double* G, double* JAC, double* JAC2);
+
+/*
  * Arm-arm collision rows of DualKinovaOptimizer::eval_g / eval_jac_g
  * (Examples/Kinova/CollisionAvoidanceTrajectory/src/DualKinovaOptimizer.cpp:269-305, 449-510): for two Kinova problems with
  * the same N, per sample the four pairs (tapered capsule 1, 2 of robot 1) x (tapered capsule 1, 2 of robot 2), each capsule

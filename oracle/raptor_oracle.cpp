@@ -1733,6 +1733,50 @@ int oracle_capsule_distance_batch(const double* P, const double* dP, const doubl
     return oracle_capsule_distance_batch_host(P, dP, R, n_pairs, F, dist, grad);
 }
 
+// *MultipleStepPeriodicityConstraints::compute for the link between step s (pr_curr, created with its reset-map block) and step
+// s + 1 (pr_next): g [B][mp], pg_pz [B][mp][n_curr], and the rows of pg3_pz2 / pg4_pz2 [B][2 Nact][n_next]
+int oracle_step_link_eval_batch_host(raptor_problem* pr_curr, raptor_problem* pr_next, const double* Zc, const double* Zn, int B,
+                                     unsigned flags, double* G, double* JAC, double* JAC2) {
+    ORACLE_TRY
+    if (!pr_curr || !pr_next || (B > 0 && (!Zc || !Zn))) throw std::invalid_argument("null argument");
+    Problem &pc = pr_curr->p, &pn = pr_next->p;
+    PeriodicityConstraints* pk = pc.cons.empty() ? nullptr : dynamic_cast<PeriodicityConstraints*>(pc.cons.back().get());
+    if (!pk) throw std::invalid_argument("step link: the current step's problem must be created with its reset-map block");
+    if (pc.traj.varLength != pn.traj.varLength || pc.traj.Nact != pn.traj.Nact)
+        throw std::invalid_argument("currTrajPtr_ and nextTrajPtr_ should have the same varLength");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && (!JAC || !JAC2)) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && !G) throw std::invalid_argument("G buffer is null");
+    const int mp = pk->m, n = pc.traj.varLength, n2 = pn.traj.varLength, ni = pc.traj.Nact;
+    for (int b = 0; b < B; b++) {
+        pk->next_traj = &pn.traj;
+        pk->next_z = Zn + (size_t)b * n2;
+        try {
+            pk->compute(Zc + (size_t)b * n, jac);
+        } catch (...) {
+            pk->next_traj = nullptr;
+            throw;
+        }
+        pk->next_traj = nullptr;
+        if (flags & RAPTOR_EVAL_G)
+            for (int r = 0; r < mp; r++) G[(size_t)b * mp + r] = pk->g[r];
+        if (jac) {
+            for (int r = 0; r < mp; r++)
+                for (int c = 0; c < n; c++) JAC[((size_t)b * mp + r) * n + c] = pk->pg_pz(r, c);
+            for (int r = 0; r < ni; r++)
+                for (int c = 0; c < n2; c++) {
+                    JAC2[((size_t)b * 2 * ni + r) * n2 + c] = pk->pg3_pz2(r, c);
+                    JAC2[((size_t)b * 2 * ni + ni + r) * n2 + c] = pk->pg4_pz2(r, c);
+                }
+        }
+    }
+    ORACLE_CATCH
+}
+int oracle_step_link_eval_batch(raptor_problem* pr_curr, raptor_problem* pr_next, const double* Zc, const double* Zn, int B,
+                                unsigned flags, double* G, double* JAC, double* JAC2, void*) {
+    return oracle_step_link_eval_batch_host(pr_curr, pr_next, Zc, Zn, B, flags, G, JAC, JAC2);
+}
+
 // Arm-arm rows of DualKinovaOptimizer::eval_g / eval_jac_g
 // (Examples/Kinova/CollisionAvoidanceTrajectory/src/DualKinovaOptimizer.cpp:269-305, 449-510)
 int oracle_dual_kinova_arm_arm_batch_host(raptor_problem* pr1, raptor_problem* pr2, const double* Z, int B, unsigned flags,

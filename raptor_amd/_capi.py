@@ -221,7 +221,7 @@ EXPORTS = [
     "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
-    "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host",
+    "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host", "step_link_eval_batch", "step_link_eval_batch_host",
 ]
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
 DEVICE_ONLY_EXPORTS = ["probe_fill"]
@@ -261,6 +261,8 @@ class CApi:
         f("eval_costs_host").argtypes = [vp, _dp, C.c_int, C.c_int, _ip, _dp, _dp]
         f("dual_kinova_arm_arm_batch").argtypes = [vp, vp, vp, C.c_int, C.c_uint, vp, vp, vp]
         f("dual_kinova_arm_arm_batch_host").argtypes = [vp, vp, _dp, C.c_int, C.c_uint, _dp, _dp]
+        f("step_link_eval_batch").argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, vp, vp, vp, vp]
+        f("step_link_eval_batch_host").argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_uint, _dp, _dp, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         if prefix == "raptor_":
@@ -296,6 +298,17 @@ class CApi:
         J = np.empty((B, rows, nvars)) if flags & EVAL_JAC else None
         self.check(self._f("dual_kinova_arm_arm_batch_host")(p1.handle, p2.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J)))
         return G, J
+
+    def step_link_host(self, curr: "ProblemHandle", nxt: "ProblemHandle", Zc, Zn, mp: int, ni: int, flags: int = EVAL_G | EVAL_JAC):
+        """*MultipleStepPeriodicityConstraints between two walking steps: g [B][mp], pg_pz [B][mp][n], (pg3_pz2; pg4_pz2) [B][2 ni][n]."""
+        n = curr.n
+        Zc, Zn = _f64(Zc).reshape(-1, n), _f64(Zn).reshape(-1, n)
+        B = Zc.shape[0]
+        G = np.empty((B, mp)) if flags & EVAL_G else None
+        J = np.empty((B, mp, n)) if flags & EVAL_JAC else None
+        J2 = np.empty((B, 2 * ni, n)) if flags & EVAL_JAC else None
+        self.check(self._f("step_link_eval_batch_host")(curr.handle, nxt.handle, _ptr(Zc), _ptr(Zn), B, flags, _ptr(G), _ptr(J), _ptr(J2)))
+        return G, J, J2
 
     def capsule_distance_host(self, P, dP, R):
         P = _f64(P).reshape(-1, 4, 3)

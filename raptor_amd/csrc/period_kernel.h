@@ -170,8 +170,15 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
                                                                    const double* __restrict__ basis, const DevLayout L,
                                                                    const double* __restrict__ Z, const double* __restrict__ core,
                                                                    const double* __restrict__ loops,
-                                                                   const double* __restrict__ ploops, double* __restrict__ G,
-                                                                   double* __restrict__ JAC) {
+                                                                   const double* __restrict__ ploops, const int mrows,
+                                                                   const int roff, const DevTraj* __restrict__ T2,
+                                                                   const double* __restrict__ basis2,
+                                                                   const double* __restrict__ Z2, double* __restrict__ G,
+                                                                   double* __restrict__ JAC, double* __restrict__ JAC2) {
+    // Z2 == nullptr: the single-step block, rows roff.. of the problem's mrows rows.  Z2 != nullptr: the link between this
+    // walking step and the next one (*MultipleStepPeriodicityConstraints.cpp:140-160): the reset rows compare the next step's
+    // first sample (its own decision vector Z2, trajectory tables T2 / basis2) with q-, v+, and their derivative with respect to
+    // Z2 goes to JAC2 [B][2 Nact][n2]
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int g = tid & 63;
@@ -185,7 +192,8 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     const double* recN = core + (size_t)(b * N + N - 1) * Q->c_stride;
     const double* pl = (P->nloops > 0) ? ploops + (size_t)b * P->loop_stride : nullptr;
     const int cv = n - nv - nd, cl = n - nd;
-    const size_t rowbase = (size_t)b * L.m + P->off;
+    const size_t rowbase = (size_t)b * mrows + roff;
+    const bool link = Z2 != nullptr;
     const bool on = g < nj;
     const int gj = on ? g : 0;
     const int jnt = P->lane_joint[gj];
@@ -443,9 +451,17 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
             }
             // (3) position reset, (4) velocity reset   (:130-144)
             if (g < ni) {
-                const int a = P->id1[g], c = P->id2[g];
-                G[rowbase + nv + nd + g] = rec0[Q->c_q + a] + P->sign * recN[Q->c_q + c];
-                G[rowbase + nv + nd + ni + g] = rec0[Q->c_v + a] + P->sign * z[cv + c];
+                if (link) {
+                    double qn, vn, an;
+                    traj_joint(T2, basis2, Z2 + b * T2->varLength, 0, g, qn, vn, an);
+                    const int j = Q->ind_joint[g];
+                    G[rowbase + nv + nd + g] = qn - recN[Q->c_q + j];
+                    G[rowbase + nv + nd + ni + g] = vn - z[cv + j];
+                } else {
+                    const int a = P->id1[g], c = P->id2[g];
+                    G[rowbase + nv + nd + g] = rec0[Q->c_q + a] + P->sign * recN[Q->c_q + c];
+                    G[rowbase + nv + nd + ni + g] = rec0[Q->c_v + a] + P->sign * z[cv + c];
+                }
             }
             // (5) contact constraints on the impact impulse   (:152-179)
             if (g == 0) {
@@ -563,8 +579,9 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
 
     // ---- phase D: Bernstein weights of the first and last sample, d g5, then the dense rows ----
     if (lead && g < K) {
-        lds[PL_W + g] = basis[g];                                 // B_k(t_0)
-        lds[PL_W + 16 + g] = basis[K + g];                        // dB_k(t_0)
+        const double* b0 = link ? basis2 : basis;                 // the first sample is the next step's in a link
+        lds[PL_W + g] = b0[g];                                    // B_k(t_0)
+        lds[PL_W + 16 + g] = b0[K + g];                           // dB_k(t_0)
         lds[PL_W + 32 + g] = basis[(size_t)((N - 1) * 3) * K + g];      // B_k(t_N-1)
         lds[PL_W + 48 + g] = basis[(size_t)((N - 1) * 3 + 1) * K + g];  // dB_k(t_N-1)
     }
@@ -588,7 +605,8 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     // pairs contiguous across the lanes, no per-element index arithmetic
     const int ndyn = ni * K;
     double* out = JAC + rowbase * n;
-    const bool pairok = ((n & 1) == 0) && ((reinterpret_cast<size_t>(JAC) & 15) == 0);
+    const bool pairok2 = ((n & 1) == 0) && ((reinterpret_cast<size_t>(JAC) & 15) == 0) && ((reinterpret_cast<size_t>(JAC2) & 15) == 0);
+    const bool pairok = pairok2;
     const int wdt = pairok ? 2 : 1;
     const int ncp = (n + wdt - 1) / wdt;
     const double* D1s = lds + PL_D1;
@@ -627,20 +645,22 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
                 v[h] = (kind[h] == 0) ? G2s[d * ni + t[h]] * wn0[h] : ((kind[h] == 1) ? JAs[d * nv + a[h]] : 0.0);
             PUT(v[0], v[1])
         }
-        for (int i = 0; i < ni; i++) {  // pg3_pz (:137)
-            const int t1 = Q->joint_ind[P->id1[i]], t2 = Q->joint_ind[P->id2[i]];
+        for (int i = 0; i < ni; i++) {  // pg3_pz (:137; link: -pq_pz(last) rows of the independent joints)
+            const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], t2 = link ? i : Q->joint_ind[P->id2[i]];
+            const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
-                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w00[h] : 0.0) + ((t[h] == t2) ? sgn * wn0[h] : 0.0) : 0.0;
+                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w00[h] : 0.0) + ((t[h] == t2) ? s2 * wn0[h] : 0.0) : 0.0;
             PUT(v[0], v[1])
         }
-        for (int i = 0; i < ni; i++) {  // pg4_pz (:148)
-            const int t1 = Q->joint_ind[P->id1[i]], j2 = P->id2[i];
+        for (int i = 0; i < ni; i++) {  // pg4_pz (:148; link: -pv_plus_pz rows of the independent joints)
+            const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], j2 = link ? Q->ind_joint[i] : P->id2[i];
+            const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
-                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w01[h] : 0.0) : ((kind[h] == 1 && a[h] == j2) ? sgn : 0.0);
+                v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w01[h] : 0.0) : ((kind[h] == 1 && a[h] == j2) ? s2 : 0.0);
             PUT(v[0], v[1])
         }
         for (int i = 0; i < 7; i++) {  // pg5_pz (:181-204)
@@ -650,6 +670,17 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
             PUT(v[0], v[1])
         }
 #undef PUT
+        if (link) {  // pg3_pz2, pg4_pz2: pq_pz(0), pq_d_pz(0) of the next step (same column layout as this step's z)
+            double* o2 = JAC2 + (size_t)b * 2 * ni * n + c0;
+            for (int i = 0; i < 2 * ni; i++) {
+                const int ti = (i < ni) ? i : i - ni;
+                double v[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) v[h] = (kind[h] == 0 && t[h] == ti) ? ((i < ni) ? w00[h] : w01[h]) : 0.0;
+                if (pairok2) store2_stream(o2, v[0], v[1]); else o2[0] = v[0];
+                o2 += n;
+            }
+        }
     }
 }
 

@@ -375,34 +375,41 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
-                   hipEvent_t between) {
-    launch_legged_core(p, dZ, B, dG, jac, st);
-    if (p.has_period && B > 0) {  // reset-map block: once per decision vector, from the first and last samples' records
-        const double* d_pl = nullptr;
-        if (p.has_digit) {
-            p.s_ploops.ensure((size_t)B * p.hper.loop_stride);
-            const long long total = (long long)B * 2;
-            const unsigned lgrid = (unsigned)((total + 63) / 64);
-            hipLaunchKernelGGL((digit_period_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
-                               p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
-            hipLaunchKernelGGL((digit_period_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
-                               p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
-            d_pl = p.s_ploops.p;
-        }
-        const bool small = p.hleg.nv <= 18 && p.hleg.nd <= 6;  // Talos / G1; Digit takes the 36 / 24 instance
+// reset-map block: once per decision vector, from the first and last samples' records of launch_legged_core.
+// next / dZ2 / dJ2 non-null: the multiple-step link form (period_kernel.h)
+void launch_period(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st, int mrows, int roff,
+                   raptor_problem* next, const double* dZ2, double* dJ2) {
+    const double* d_pl = nullptr;
+    if (p.has_digit) {
+        p.s_ploops.ensure((size_t)B * p.hper.loop_stride);
+        const long long total = (long long)B * 2;
+        const unsigned lgrid = (unsigned)((total + 63) / 64);
+        hipLaunchKernelGGL((digit_period_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
+                           p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
+        hipLaunchKernelGGL((digit_period_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
+                           p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
+        d_pl = p.s_ploops.p;
+    }
+    const DevTraj* T2 = next ? next->d_traj.p : nullptr;
+    const double* basis2 = next ? next->d_basis.p : nullptr;
+    const bool small = p.hleg.nv <= 18 && p.hleg.nd <= 6;  // Talos / G1; Digit takes the 36 / 24 instance
 #define PERIOD_LAUNCH(NVM_, NDM_, DV_, dJ_)                                                                              \
     hipLaunchKernelGGL((legged_period_kernel<NVM_, NDM_, DV_>), dim3((unsigned)B), dim3(PL_BLOCK),                          \
                        (size_t)period_lds_doubles(NVM_, NDM_) * sizeof(double), st, p.d_model.p, p.d_traj.p, p.d_leg.p,    \
-                       p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, dG, dJ_)
-        if (small) {
-            if (jac) PERIOD_LAUNCH(18, 6, true, dJ); else PERIOD_LAUNCH(18, 6, false, nullptr);
-        } else {
-            if (jac) PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, true, dJ); else PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, false, nullptr);
-        }
-#undef PERIOD_LAUNCH
-        HIP_CHECK(hipGetLastError());
+                       p.d_per.p, p.d_basis.p, p.layout, dZ, p.s_core.p, p.s_loops.p, d_pl, mrows, roff, T2, basis2, dZ2, dG, dJ_, dJ2)
+    if (small) {
+        if (jac) PERIOD_LAUNCH(18, 6, true, dJ); else PERIOD_LAUNCH(18, 6, false, nullptr);
+    } else {
+        if (jac) PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, true, dJ); else PERIOD_LAUNCH(RAPTOR_MAX_NV, 24, false, nullptr);
     }
+#undef PERIOD_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
+                   hipEvent_t between) {
+    launch_legged_core(p, dZ, B, dG, jac, st);
+    if (p.has_period && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
     if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
     const long long E = (long long)B * p.htraj.N;
@@ -1427,6 +1434,26 @@ int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const d
     API_CATCH
 }
 
+// *MultipleStepPeriodicityConstraints (DigitMultipleStepPeriodicityConstraints.cpp:57-230, Talos / G1 twins)
+static void step_link_device(raptor_problem& pc, raptor_problem& pn, const double* dZc, const double* dZn, int B, unsigned flags,
+                             double* dG, double* dJ, double* dJ2, hipStream_t st) {
+    if (pc.kind != 2 || pn.kind != 2 || !pc.has_period)
+        throw std::invalid_argument("step link: legged problems, the current step's created with its reset-map block");
+    if (pc.layout.n != pn.layout.n || pc.htraj.Nact != pn.htraj.Nact || pc.htraj.K != pn.htraj.K)
+        throw std::invalid_argument("currTrajPtr_ and nextTrajPtr_ should have the same varLength");
+    if (!(flags & (RAPTOR_EVAL_G | RAPTOR_EVAL_JAC))) throw std::invalid_argument("flags: nothing to evaluate");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && (dJ == nullptr || dJ2 == nullptr)) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && dG == nullptr) throw std::invalid_argument("G buffer is null");
+    if (B < 0) throw std::invalid_argument("negative batch size");
+    if (B == 0) return;
+    if (dZc == nullptr || dZn == nullptr) throw std::invalid_argument("Z is null");
+    check_launchable(pc, B);
+    launch_legged_core(pc, dZc, B, nullptr, jac, st);  // records only: the step's own rows belong to raptor_eval_batch
+    launch_period(pc, dZc, B, (flags & RAPTOR_EVAL_G) ? dG : nullptr, jac ? dJ : nullptr, jac, st, pc.hleg.nperiod, 0, &pn, dZn,
+                  jac ? dJ2 : nullptr);
+}
+
 // DualKinovaOptimizer.cpp:269-305, 449-510
 static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const double* dZ, int B, unsigned flags, double* dG,
                                 double* dJ, hipStream_t st) {
@@ -1462,6 +1489,42 @@ static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const do
                            (flags & RAPTOR_EVAL_G) ? dG + p0 : dDist, jac ? dJ + (size_t)p0 * 14 : nullptr);
         HIP_CHECK(hipGetLastError());
     }
+}
+
+int raptor_step_link_eval_batch(raptor_problem* curr, raptor_problem* next, const double* d_Zcurr, const double* d_Znext, int B,
+                                unsigned flags, double* d_G, double* d_JAC, double* d_JAC2, void* stream) {
+    API_TRY
+    if (!curr || !next) throw std::invalid_argument("null argument");
+    step_link_device(*curr, *next, d_Zcurr, d_Znext, B, flags, d_G, d_JAC, d_JAC2, (hipStream_t)stream);
+    API_CATCH
+}
+
+int raptor_step_link_eval_batch_host(raptor_problem* curr, raptor_problem* next, const double* Zcurr, const double* Znext, int B,
+                                     unsigned flags, double* G, double* JAC, double* JAC2) {
+    API_TRY
+    if (!curr || !next) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("negative batch size");
+    if (B > 0 && (!Zcurr || !Znext)) throw std::invalid_argument("Z is null");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
+    if (jac && (!JAC || !JAC2)) throw std::invalid_argument("JAC buffer is null");
+    if ((flags & RAPTOR_EVAL_G) && !G) throw std::invalid_argument("G buffer is null");
+    if (B == 0) return RAPTOR_OK;
+    const size_t n = curr->layout.n, mp = curr->hleg.nperiod, r2 = 2 * (size_t)curr->hleg.ni;
+    curr->s_Z.ensure((size_t)B * n * 2);
+    curr->s_G.ensure((size_t)B * mp);
+    if (jac) curr->s_J.ensure((size_t)B * (mp + r2) * n);
+    HIP_CHECK(hipMemcpy(curr->s_Z.p, Zcurr, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(curr->s_Z.p + (size_t)B * n, Znext, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+    double* dJ = jac ? curr->s_J.p : nullptr;
+    double* dJ2 = jac ? curr->s_J.p + (size_t)B * mp * n : nullptr;
+    step_link_device(*curr, *next, curr->s_Z.p, curr->s_Z.p + (size_t)B * n, B, flags, curr->s_G.p, dJ, dJ2, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (flags & RAPTOR_EVAL_G) HIP_CHECK(hipMemcpy(G, curr->s_G.p, (size_t)B * mp * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac) {
+        HIP_CHECK(hipMemcpy(JAC, dJ, (size_t)B * mp * n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(JAC2, dJ2, (size_t)B * r2 * n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    API_CATCH
 }
 
 int raptor_dual_kinova_arm_arm_batch(raptor_problem* p1, raptor_problem* p2, const double* d_Z, int B, unsigned flags,

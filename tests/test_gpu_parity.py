@@ -591,6 +591,39 @@ def test_constrained_initial_state(oracle, hip, robot, vel):
     check(Dh, Do)
 
 
+@pytest.mark.parametrize("robot,stance", [("talos", "L"), ("g1", "R"), ("digit", "L"), ("digit", "R")])
+def test_step_link_block(oracle, hip, robot, stance):
+    """*MultipleStepPeriodicityConstraints: the block between walking step s and s + 1 (g, pg_pz w.r.t. this step's z, pg3_pz2 /
+    pg4_pz2 w.r.t. the next step's z), G-only and full evaluation."""
+    other = "R" if stance == "L" else "L"
+    keep = []
+    N = 5
+    mk = (lambda api, st, per: H.digit_problem(api, keep, N=N, stance=st, periodic=per)) if robot == "digit" else \
+         (lambda api, st, per: H.legged_problem(api, robot, keep, N=N, stance=st, periodic=per))
+    (oc, m, cfg), (on, _, _) = mk(oracle, stance, True), mk(oracle, other, False)
+    (hc, _, _), (hn, _, _) = mk(hip, stance, True), mk(hip, other, False)
+    mp, ni = m.nv + len(cfg.dependent_ids) + 24 + 7, 12
+    rng = np.random.default_rng(33)
+    Zc = 0.1 * rng.uniform(-1, 1, (6, oc.n))
+    Zn = 0.1 * rng.uniform(-1, 1, (6, oc.n))
+    Zc[:, -6:] *= 30.0
+    Go, Jo, J2o = oracle.step_link_host(oc, on, Zc, Zn, mp, ni)
+    Gh, Jh, J2h = hip.step_link_host(hc, hn, Zc, Zn, mp, ni)
+    check(Gh, Go)
+    check(Jh, Jo)
+    check(J2h, J2o, 1e-13)
+    Gh2, a, b = hip.step_link_host(hc, hn, Zc, Zn, mp, ni, A.EVAL_G)
+    assert a is None and b is None
+    check(Gh2, Gh, 1e-13)
+    # the step's own evaluation is undisturbed by a link evaluation in between
+    G1, J1 = hc.eval_host(Zc)
+    hip.step_link_host(hc, hn, Zc[::-1].copy(), Zn, mp, ni)
+    G2, J2 = hc.eval_host(Zc)
+    assert np.array_equal(G1, G2) and np.array_equal(J1, J2)
+    with pytest.raises(A.RaptorInvalidArgument):  # the current step's problem needs its reset-map tables
+        hip.step_link_host(hn, hc, Zc, Zn, mp, ni)
+
+
 def test_legged_ragged_and_degenerate_sizes(oracle, hip):
     """Odd batch x odd sample counts (half-filled wavefronts), N = 1, an empty batch, and error codes."""
     keep = []

@@ -243,3 +243,58 @@ def test_bezier_constrained_initial_state(oracle, kinova):
             assert np.abs(fd[0] - ptau[0, :, :, c]).max() < 1e-5 * (1 + np.abs(ptau[0, :, :, c]).max())
     with pytest.raises(A.RaptorInvalidArgument):  # "initial position must be constrained first"
         H.id_problem(oracle, kinova, keep, ttype=A.TRAJ_BEZIER, degree=5, q_d0=qd0)
+
+
+@pytest.mark.parametrize("robot", ["talos", "digit"])
+def test_step_link_block_fd(oracle, robot):
+    """*MultipleStepPeriodicityConstraints (DigitMultipleStepPeriodicityConstraints.cpp:57-230): the link between walking step s
+    and s + 1.  Same rows as the single-step block except the reset rows; gradient w.r.t. both steps' variables by central
+    differences, and the reset rows vanish when the next step starts where this one ends."""
+    from raptor_amd import _capi as A
+
+    keep = []
+    N = 4
+    if robot == "digit":
+        pc, m, cfg = H.digit_problem(oracle, keep, N=N, stance="L", periodic=True)
+        pn, _, _ = H.digit_problem(oracle, keep, N=N, stance="R")
+    else:
+        pc, m, cfg = H.legged_problem(oracle, robot, keep, N=N, stance="L", periodic=True)
+        pn, _, _ = H.legged_problem(oracle, robot, keep, N=N, stance="R")
+    nv, nd, ni = m.nv, len(cfg.dependent_ids), 12
+    mp = nv + nd + 2 * ni + 7
+    rng = np.random.default_rng(21)
+    Zc = 0.1 * rng.uniform(-1, 1, (1, pc.n))
+    Zn = 0.1 * rng.uniform(-1, 1, (1, pc.n))
+    G, J, J2 = oracle.step_link_host(pc, pn, Zc, Zn, mp, ni)
+    # rows 0 .. nv + nd and the contact rows are the single-step block's
+    Gs, Js = pc.eval_host(Zc)
+    off = pc.block_offsets[-2]
+    keep_rows = list(range(nv + nd)) + list(range(nv + nd + 2 * ni, mp))
+    assert np.abs(G[0, keep_rows] - Gs[0, off:][keep_rows]).max() < 1e-12
+    assert np.abs(J[0, keep_rows] - Js[0, off:][keep_rows]).max() < 1e-12
+    h = 1e-6
+    for c in list(range(0, pc.n, 9)) + list(range(pc.n - nv - nd, pc.n - nd, 5)):
+        zp, zm = Zc.copy(), Zc.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        fd = (oracle.step_link_host(pc, pn, zp, Zn, mp, ni, A.EVAL_G)[0] - oracle.step_link_host(pc, pn, zm, Zn, mp, ni, A.EVAL_G)[0]) / (2 * h)
+        assert np.abs(fd[0] - J[0, :, c]).max() < 1e-5 * (1 + np.abs(J[0, :, c]).max()), c
+    r3 = slice(nv + nd, nv + nd + 2 * ni)
+    for c in range(0, pc.n, 5):
+        zp, zm = Zn.copy(), Zn.copy()
+        zp[0, c] += h
+        zm[0, c] -= h
+        fd = (oracle.step_link_host(pc, pn, Zc, zp, mp, ni, A.EVAL_G)[0] - oracle.step_link_host(pc, pn, Zc, zm, mp, ni, A.EVAL_G)[0]) / (2 * h)
+        assert np.abs(fd[0, r3] - J2[0, :, c]).max() < 1e-6, c
+        assert np.abs(np.delete(fd[0], np.arange(nv + nd, nv + nd + 2 * ni))).max() < 1e-9
+    # continuity: next step's first Bezier coefficient = q-, its velocity = v+ -> reset rows are zero
+    K = cfg.degree + 1
+    r = pc.constrained_id_host(Zc, N, nv, ni, derivatives=False)
+    ind = cfg.independent_ids
+    Zn2 = Zn.copy()
+    vplus = Zc[0, pc.n - nv - nd:pc.n - nd]
+    for t in range(ni):
+        Zn2[0, t * K] = r["q"][0, N - 1, ind[t]]
+        Zn2[0, t * K + 1] = Zn2[0, t * K] + vplus[ind[t]] * cfg.T / cfg.degree
+    G2, _, _ = oracle.step_link_host(pc, pn, Zc, Zn2, mp, ni, A.EVAL_G)
+    assert np.abs(G2[0, r3]).max() < 1e-12
