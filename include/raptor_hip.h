@@ -121,8 +121,9 @@ typedef struct raptor_gait_desc {
  * with q-, v- the last sample, J the constraint Jacobian after the stance swap, v+ = z.segment(varLength - nv - n_dep, nv)
  * and lambda = z.tail(n_dep): `extra_variables` must be nv + n_dep.  `enabled == 0` leaves the block out.
  */
+#define RAPTOR_PERIOD_LINK_ONLY 2   /* period.enabled: build the tables for raptor_step_link_eval_batch, add no rows */
 typedef struct raptor_period_desc {
-    int enabled;
+    int enabled;                    /* 0: absent, 1: the single-step block, RAPTOR_PERIOD_LINK_ONLY (multiple-step members) */
     int swing_contact_joint_id;     /* contact_joint_id after dcPtr_->reinitialize() (Pinocchio id); Digit: derived    */
     double swing_foot_endT_p[3];    /* stance_foot_endT.p after the swap; Digit: compiled in                           */
     const int* joint_id1;           /* [num_independent] getJointId(JOINT_MAP[i][0]) - 1; Digit: derived               */

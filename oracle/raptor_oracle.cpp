@@ -1011,6 +1011,7 @@ struct Problem {
     ContactDynamicsConstraints dc;
     ConstrainedInverseDynamics cid;
     std::vector<std::unique_ptr<Constraints>> cons;  // constraintsPtrVec_ order
+    std::unique_ptr<Constraints> link;  // reset-map tables kept for the multiple-step link only (period.enabled == RAPTOR_PERIOD_LINK_ONLY)
     int n = 0, m = 0;
     std::vector<int> offsets;
     void finish() {
@@ -1365,9 +1366,10 @@ int oracle_legged_problem_create(const raptor_model* model, const raptor_legged_
         std::vector<int> id1(pd.joint_id1, pd.joint_id1 + dc.ni), id2(pd.joint_id2, pd.joint_id2 + dc.ni);
         for (int k = 0; k < dc.ni; k++)
             if (id1[k] < 0 || id1[k] >= nv || id2[k] < 0 || id2[k] >= nv) throw std::runtime_error("Can not find joint");
-        p.cons.emplace_back(new PeriodicityConstraints(
+        std::unique_ptr<Constraints> pc(new PeriodicityConstraints(
             &p.cid, d->mu, d->gamma, d->Lx, d->Ly, pd.mirror_sign, id1, id2, pd.swing_contact_joint_id,
             Transform(Vec3(pd.swing_foot_endT_p[0], pd.swing_foot_endT_p[1], pd.swing_foot_endT_p[2]))));
+        if (pd.enabled == RAPTOR_PERIOD_LINK_ONLY) p.link = std::move(pc); else p.cons.push_back(std::move(pc));
     }
     p.finish();
     *out = pr.release();
@@ -1492,8 +1494,10 @@ int oracle_digit_problem_create(const raptor_model* model, const raptor_digit_de
                 id1.push_back(d->leg_ids[leg][DIGIT_LEG_INDEPENDENT[k]]);
                 id2.push_back(d->leg_ids[1 - leg][DIGIT_LEG_INDEPENDENT[k]]);
             }
-        p.cons.emplace_back(new PeriodicityConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly, 1.0, id1, id2,
-                                                       d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1, Transform(Re, Vec3(pp[0], pp[1], pp[2]))));
+        std::unique_ptr<Constraints> pc(new PeriodicityConstraints(&p.cid, d->mu, d->gamma, d->Lx, d->Ly, 1.0, id1, id2,
+                                                                   d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1,
+                                                                   Transform(Re, Vec3(pp[0], pp[1], pp[2]))));
+        if (d->period.enabled == RAPTOR_PERIOD_LINK_ONLY) p.link = std::move(pc); else p.cons.push_back(std::move(pc));
     }
     p.finish();
     *out = pr.release();
@@ -1740,7 +1744,8 @@ int oracle_step_link_eval_batch_host(raptor_problem* pr_curr, raptor_problem* pr
     ORACLE_TRY
     if (!pr_curr || !pr_next || (B > 0 && (!Zc || !Zn))) throw std::invalid_argument("null argument");
     Problem &pc = pr_curr->p, &pn = pr_next->p;
-    PeriodicityConstraints* pk = pc.cons.empty() ? nullptr : dynamic_cast<PeriodicityConstraints*>(pc.cons.back().get());
+    PeriodicityConstraints* pk = pc.link ? dynamic_cast<PeriodicityConstraints*>(pc.link.get())
+                                         : (pc.cons.empty() ? nullptr : dynamic_cast<PeriodicityConstraints*>(pc.cons.back().get()));
     if (!pk) throw std::invalid_argument("step link: the current step's problem must be created with its reset-map block");
     if (pc.traj.varLength != pn.traj.varLength || pc.traj.Nact != pn.traj.Nact)
         throw std::invalid_argument("currTrajPtr_ and nextTrajPtr_ should have the same varLength");

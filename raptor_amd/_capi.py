@@ -125,7 +125,7 @@ def _period(cfg, keep: list) -> "PeriodDesc":
     pp = getattr(cfg, "period", None)
     if pp is None:
         return d
-    d.enabled = 1
+    d.enabled = int(pp.get("enabled", 1))  # 2 = RAPTOR_PERIOD_LINK_ONLY
     d.swing_contact_joint_id = int(pp.get("swing_contact_joint_id", 0))
     d.swing_foot_endT_p = (C.c_double * 3)(*[float(x) for x in pp.get("swing_foot_endT_p", (0, 0, 0))])
     if "joint_id1" in pp:

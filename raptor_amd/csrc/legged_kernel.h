@@ -734,7 +734,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(cons
     const long long br = w / n;
     const int r = (int)(br % L.m);
     const long long b = br / L.m;
-    if (Q->nperiod > 0 && r >= Q->off_period) return;  // the reset-map rows are written by legged_period_kernel
+    if (Q->nperiod > 0 && r >= Q->off_period) return;  // the reset-map rows (if part of this problem) are written by legged_period_kernel
     double val = 0.0;
     if (c < ni * K) {
         const int t = c / K, k = c - t * K;

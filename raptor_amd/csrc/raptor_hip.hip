@@ -106,7 +106,8 @@ struct raptor_problem {
     DevBuf<int> d_kinds;
     DevBuf<DevCustRow> d_cust;       // customized block: row specs by row, per-sample row lists
     DevBuf<int> d_cust_list, d_cust_start;
-    bool has_period = false;         // reset-map block (period_kernel.h)
+    bool has_period = false;         // reset-map tables present (period_kernel.h)
+    bool period_rows = false;        // ... and the block is part of this problem's rows
     DevPeriod hper;
     DevBuf<DevPeriod> d_per;
     DevBuf<double> s_ploops;         // per-z closed-loop records of the reset-map block (Digit)
@@ -409,7 +410,7 @@ void launch_period(raptor_problem& p, const double* dZ, int B, double* dG, doubl
 void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
                    hipEvent_t between) {
     launch_legged_core(p, dZ, B, dG, jac, st);
-    if (p.has_period && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
+    if (p.period_rows && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
     if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
     const long long E = (long long)B * p.htraj.N;
@@ -659,7 +660,7 @@ struct LeggedSetup {
     double sf_R[9], sf_p[3];            // swing-foot end transform
     raptor_gait_desc gait;
     // reset-map block
-    bool period = false;
+    bool period = false, period_rows = false;   // tables; rows in this problem (false: link only)
     int period_contact_joint_id = 0;    // Pinocchio id of the stance foot after reinitialize()
     double period_endR[9], period_endp[3];
     std::vector<int> period_id1, period_id2;
@@ -868,6 +869,7 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     std::memset(&p->hspheres, 0, sizeof(p->hspheres));
     // reset-map block (*SingleStepPeriodicityConstraints.cpp:12-16): nv + n_dep + Nact + Nact + 7 rows, last
     Q.nperiod = S.period ? nv + nd + 2 * ni + 7 : 0;
+    const int prow = S.period_rows ? Q.nperiod : 0;
     Q.off_period = rt + rq + rcn + Q.ncust;
     if (S.period) {
         if (S.extra_variables != nv + nd) throw std::invalid_argument("periodicity constraints need v_reset and lambda_reset in z");
@@ -934,15 +936,16 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
         P.loop_stride = (off + 1) & ~1;
         p->d_per.upload(&P, 1);
         p->has_period = true;
+        p->period_rows = S.period_rows;
     }
-    p->layout = DevLayout{rt + rq + rcn + Q.ncust + Q.nperiod, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
+    p->layout = DevLayout{rt + rq + rcn + Q.ncust + prow, p->htraj.varLength, Q.off_q, -1, Q.off_tau, -1};
     p->num_blocks = 3;
     p->block_offsets[0] = 0; p->block_offsets[1] = rt; p->block_offsets[2] = rt + rq; p->block_offsets[3] = rt + rq + rcn;
     if (S.cust) p->block_offsets[++p->num_blocks] = rt + rq + rcn + Q.ncust;
-    if (S.period) p->block_offsets[++p->num_blocks] = rt + rq + rcn + Q.ncust + Q.nperiod;
+    if (S.period_rows) p->block_offsets[++p->num_blocks] = rt + rq + rcn + Q.ncust + prow;
     p->g_lb.assign(p->layout.m, 0.0);
     p->g_ub.assign(p->layout.m, 0.0);
-    if (S.period) {  // *SingleStepPeriodicityConstraints.cpp:217-226: equalities, then the seven contact rows
+    if (S.period_rows) {  // *SingleStepPeriodicityConstraints.cpp:217-226: equalities, then the seven contact rows
         const int o5 = Q.off_period + nv + nd + 2 * ni;
         p->g_ub[o5] = 1e19;
         for (int k = 1; k < 7; k++) p->g_lb[o5 + k] = -1e19;
@@ -1040,6 +1043,7 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
     if (d->period.enabled) {  // TalosSingleStepOptimizer.cpp:101-106
         if (!d->period.joint_id1 || !d->period.joint_id2) throw std::invalid_argument("null argument");
         S.period = true;
+        S.period_rows = d->period.enabled != RAPTOR_PERIOD_LINK_ONLY;
         S.period_contact_joint_id = d->period.swing_contact_joint_id;
         for (int k = 0; k < 9; k++) S.period_endR[k] = (k % 4 == 0) ? 1.0 : 0.0;
         for (int k = 0; k < 3; k++) S.period_endp[k] = d->period.swing_foot_endT_p[k];
@@ -1184,6 +1188,7 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
     }
     if (d->period.enabled) {  // DigitSingleStepOptimizer.cpp:102-106, JOINT_MAP of DigitSingleStepPeriodicityConstraints.h:19-32
         S.period = true;
+        S.period_rows = d->period.enabled != RAPTOR_PERIOD_LINK_ONLY;
         S.period_contact_joint_id = d->leg_ids[1 - sleg][DG_TOE_ROLL] + 1;
         digit_stance_foot_endT(1 - sleg, S.period_endR, S.period_endp);  // DigitDynamicsConstraints.cpp:81-95 after the swap
         for (int leg = 0; leg < 2; leg++)

@@ -68,7 +68,9 @@ def legged_problem(api, which, keep, N=14, stance="L", T_des=None, degree=None, 
     if customized:
         cfg.gait = (robots.talos_gait if which == "talos" else robots.g1_gait)(m, stance)
     if periodic:
-        cfg.period = (robots.talos_period if which == "talos" else robots.g1_period)(m, stance)
+        cfg.period = dict((robots.talos_period if which == "talos" else robots.g1_period)(m, stance))
+        if periodic == "link":
+            cfg.period["enabled"] = 2  # RAPTOR_PERIOD_LINK_ONLY
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, len(cfg.independent_ids), cfg.degree, A.TIME_CHEBYSHEV, q0=q0, q_d0=q_d0)
@@ -91,7 +93,7 @@ def digit_problem(api, keep, N=14, stance="L", T_des=None, degree=None, customiz
     if customized:
         cfg.gait = robots.digit_gait()
     if periodic:
-        cfg.period = {}
+        cfg.period = {"enabled": 2} if periodic == "link" else {}
     mh = api.model_create(m)
     keep.append(mh)
     t = A.make_traj_desc(keep, A.TRAJ_BEZIER, cfg.T, N, 12, cfg.degree, A.TIME_CHEBYSHEV, q0=q0, q_d0=q_d0)

@@ -622,6 +622,14 @@ def test_step_link_block(oracle, hip, robot, stance):
     assert np.array_equal(G1, G2) and np.array_equal(J1, J2)
     with pytest.raises(A.RaptorInvalidArgument):  # the current step's problem needs its reset-map tables
         hip.step_link_host(hn, hc, Zc, Zn, mp, ni)
+    # multiple-step members are built without the single-step block's rows (periodic = false): tables only
+    (ol, _, _), (hl, _, _) = mk(oracle, stance, "link"), mk(hip, stance, "link")
+    assert hl.m == ol.m == hn.m and hl.block_offsets == ol.block_offsets
+    Gl, Jl, J2l = hip.step_link_host(hl, hn, Zc, Zn, mp, ni)
+    assert np.array_equal(Gl, Gh) and np.array_equal(Jl, Jh) and np.array_equal(J2l, J2h)
+    check(oracle.step_link_host(ol, on, Zc, Zn, mp, ni)[1], Jo, 1e-14)
+    for x, y in zip(hl.eval_host(Zc), ol.eval_host(Zc)):  # ... and the member's own rows stop before the reset map
+        check(x, y)
 
 
 def test_legged_ragged_and_degenerate_sizes(oracle, hip):

@@ -272,6 +272,13 @@ def test_step_link_block_fd(oracle, robot):
     keep_rows = list(range(nv + nd)) + list(range(nv + nd + 2 * ni, mp))
     assert np.abs(G[0, keep_rows] - Gs[0, off:][keep_rows]).max() < 1e-12
     assert np.abs(J[0, keep_rows] - Js[0, off:][keep_rows]).max() < 1e-12
+    # a multiple-step member (periodic = false in the reference) carries the tables and none of the rows
+    stance_swap = "link"
+    pl = (H.digit_problem(oracle, keep, N=N, stance="L", periodic=stance_swap) if robot == "digit" else
+          H.legged_problem(oracle, robot, keep, N=N, stance="L", periodic=stance_swap))[0]
+    assert pl.m == pn.m == pc.m - mp and pl.block_offsets == pc.block_offsets[:-1]
+    for x, y in zip(oracle.step_link_host(pl, pn, Zc, Zn, mp, ni), (G, J, J2)):
+        assert np.array_equal(x, y)
     h = 1e-6
     for c in list(range(0, pc.n, 9)) + list(range(pc.n - nv - nd, pc.n - nd, 5)):
         zp, zm = Zc.copy(), Zc.copy()
