@@ -333,6 +333,33 @@ int raptor_eval_costs(raptor_problem* problem, const double* d_Z, int B, int num
 int raptor_eval_costs_host(raptor_problem* problem, const double* Z, int B, int num_costs, const int* kinds, double* F,
                            double* GRAD);
 
+/*
+ * KinovaOptimizer's objective (Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaOptimizer.cpp:152-250):
+ *   f = 0.5 * sum_j d_j^2, d_j = q(tplan_n)(j) - q_des(j), wrapped to (-pi, pi] on the continuous joints 0, 2, 4, 6;
+ *   grad_f(j) = d_j * pq_pz(tplan_n)(j, j);  hess_f = diag(pq_pz(tplan_n)(j, j)^2) (enters raptor_eval_h_batch).
+ * _set_objective stands in for the q_des_input / tplan_n_input arguments of set_parameters (:28-29, 39-40).
+ *   Z [B][7] -> F [B], GRAD [B][7] (NULL: eval_f only)
+ */
+int raptor_kinova_set_objective(raptor_problem* problem, const double* q_des, int tplan_n);
+int raptor_kinova_eval_objective(raptor_problem* problem, const double* d_Z, int B, double* d_F, double* d_GRAD, void* hip_stream);
+int raptor_kinova_eval_objective_host(raptor_problem* problem, const double* Z, int B, double* F, double* GRAD);
+
+/*
+ * Optimizer::eval_h (Optimization/src/Optimizer.cpp:499-635) for the optimizer that enables it, KinovaOptimizer
+ * (KinovaOptimizer.cpp:37): the Hessian of the Lagrangian
+ *     obj_factor * hess_f + sum_r lambda_r * pg_pz_pz(r)
+ * over the rows of every constraint block -- Constraints::compute(z, true, true) of JointLimits / VelocityLimits (zero),
+ * TorqueLimits (InverseDynamics::ptau_pz_pz, InverseDynamics.cpp:141-171) and KinovaCustomizedConstraints
+ * (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:375-475) -- as `values`: the upper triangle row by row,
+ * iRow = i, jCol = j >= i (:531-538, :621-627).
+ *   Z [B][n], obj_factor [B] (NULL: 0 for every z, eval_hess_f is skipped as at :552), lambda [B][m] -> H [B][n (n + 1) / 2]
+ * Other problem kinds return RAPTOR_ERR_RUNTIME (the reference's eval_h returns false for them, :513-515).
+ */
+int raptor_eval_h_batch(raptor_problem* problem, const double* d_Z, int B, const double* d_obj_factor, const double* d_lambda,
+                        double* d_H, void* hip_stream);
+int raptor_eval_h_batch_host(raptor_problem* problem, const double* Z, int B, const double* obj_factor, const double* lambda,
+                             double* H);
+
 /* Measurement aid with no counterpart in the reference: `blocks` workgroups each fill one contiguous chunk of
  * `chunk_doubles` doubles with 16-byte stores -- the write pattern of the Jacobian kernels, used by scripts/bw_probe.py
  * to calibrate the achievable HBM write rate next to the roofline numbers. */

@@ -18,6 +18,7 @@
 // building and anything else without a golden vector in the reference: PARITY UNPINNED.
 // =====================================================================================
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -1002,6 +1003,7 @@ struct KinovaCustomizedConstraints : Constraints {
 #include "../raptor_amd/csrc/digit_constants.h"
 #include "../raptor_amd/csrc/digit_tables.h"
 #include "legged_oracle.inc"
+#include "hessian_oracle.inc"
 
 // ------------------------------------------------------------------ problem = Optimizer's constraint list
 struct Problem {
@@ -1012,6 +1014,9 @@ struct Problem {
     ConstrainedInverseDynamics cid;
     std::vector<std::unique_ptr<Constraints>> cons;  // constraintsPtrVec_ order
     std::unique_ptr<Constraints> link;  // reset-map tables kept for the multiple-step link only (period.enabled == RAPTOR_PERIOD_LINK_ONLY)
+    bool is_kinova = false;
+    VecX q_des;        // KinovaOptimizer::q_des, tplan_n (KinovaOptimizer.cpp:39-40); tplan_n < 0: objective not set
+    int tplan_n = -1;
     int n = 0, m = 0;
     std::vector<int> offsets;
     void finish() {
@@ -1302,6 +1307,7 @@ int oracle_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     p.cons.emplace_back(new TorqueLimits(&p.traj, &p.id, tl, tu)); // :95-99
     p.cons.emplace_back(new KinovaCustomizedConstraints(&p.traj, &p.model, d->num_obstacles, d->box_center, d->box_rpy,
                                                         d->box_size, d->include_gripper != 0, d->collision_buffer));  // :102-109
+    p.is_kinova = true;
     p.finish();
     *out = pr.release();
     ORACLE_CATCH
@@ -1686,6 +1692,122 @@ int oracle_eval_batch_host(raptor_problem* pr, const double* Z, int B, unsigned 
 }
 int oracle_eval_batch(raptor_problem* pr, const double* Z, int B, unsigned flags, double* G, double* JAC, void*) {
     return oracle_eval_batch_host(pr, Z, B, flags, G, JAC);
+}
+
+// KinovaOptimizer::set_parameters, q_des_input / tplan_n_input (KinovaOptimizer.cpp:28-29, 39-40, 112-113)
+int oracle_kinova_set_objective(raptor_problem* pr, const double* q_des, int tplan_n) {
+    ORACLE_TRY
+    if (!pr || !q_des) throw std::invalid_argument("null argument");
+    Problem& p = pr->p;
+    if (!p.is_kinova) throw std::invalid_argument("objective: not a KinovaOptimizer problem");
+    if (tplan_n < 0 || tplan_n >= p.traj.N) throw std::invalid_argument("tplan_n must be in [0, N)");
+    p.q_des.assign(q_des, q_des + p.traj.Nact);
+    p.tplan_n = tplan_n;
+    ORACLE_CATCH
+}
+
+// KinovaOptimizer::eval_f / eval_grad_f (KinovaOptimizer.cpp:152-218)
+int oracle_kinova_eval_objective_host(raptor_problem* pr, const double* Z, int B, double* F, double* GRAD) {
+    ORACLE_TRY
+    if (!pr || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    Problem& p = pr->p;
+    if (!p.is_kinova || p.tplan_n < 0) throw std::invalid_argument("objective: raptor_kinova_set_objective has not been called");
+    const int n = p.n;
+    for (int b = 0; b < B; b++) {
+        p.traj.compute(Z + (size_t)b * n, GRAD != nullptr);
+        const VecX& qplan = p.traj.q[p.tplan_n];
+        double obj = 0;
+        const int order[7] = {0, 2, 4, 6, 1, 3, 5};  // :169-175, continuous joints first
+        for (int t = 0; t < 7; t++) {
+            const int i = order[t];
+            const double d = (i % 2 == 0) ? wrapToPi(qplan[i] - p.q_des[i]) : (qplan[i] - p.q_des[i]);
+            obj += std::pow(d, 2);
+        }
+        F[b] = 0.5 * obj;  // :177
+        if (GRAD) {
+            const MatX& pqplan_pz = p.traj.pq_pz[p.tplan_n];
+            for (int i = 0; i < n; i++) {  // :206-215
+                const double qdiff = (i % 2 == 0) ? wrapToPi(qplan[i] - p.q_des[i]) : (qplan[i] - p.q_des[i]);
+                GRAD[(size_t)b * n + i] = qdiff * pqplan_pz(i, i);
+            }
+        }
+    }
+    ORACLE_CATCH
+}
+int oracle_kinova_eval_objective(raptor_problem* pr, const double* Z, int B, double* F, double* GRAD, void*) {
+    return oracle_kinova_eval_objective_host(pr, Z, B, F, GRAD);
+}
+
+// Optimizer::eval_h (Optimization/src/Optimizer.cpp:499-635) with KinovaOptimizer::eval_hess_f (KinovaOptimizer.cpp:223-250):
+// H[b] = upper triangle, row by row (:531-538, :621-627), of obj_factor * hess_f + sum_r lambda_r * pg_pz_pz(r).
+int oracle_eval_h_batch_host(raptor_problem* pr, const double* Z, int B, const double* obj_factor, const double* lambda, double* H) {
+    ORACLE_TRY
+    if (!pr || (B > 0 && (!Z || !lambda || !H))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    Problem& p = pr->p;
+    if (!p.is_kinova) throw std::runtime_error("eval_h: enable_hessian is false for this optimizer");  // :513-515 (only KinovaOptimizer sets it)
+    if (obj_factor && p.tplan_n < 0) throw std::invalid_argument("eval_h: raptor_kinova_set_objective has not been called");
+    const int n = p.n, N = p.traj.N, Nact = p.traj.Nact;
+    auto* kc = dynamic_cast<KinovaCustomizedConstraints*>(p.cons[3].get());
+    InverseDynamicsHessian idh;
+    for (int b = 0; b < B; b++) {
+        const double* z = Z + (size_t)b * n;
+        const double* lam = lambda + (size_t)b * p.m;
+        MatX hessian(n, n);
+        const double of = obj_factor ? obj_factor[b] : 0.0;
+        if (of != 0) {  // :552-563, KinovaOptimizer.cpp:243-247
+            p.traj.compute(z, true);
+            const MatX& pqplan_pz = p.traj.pq_pz[p.tplan_n];
+            for (int i = 0; i < n; i++) hessian(i, i) += of * (pqplan_pz(i, i) * pqplan_pz(i, i));
+        }
+        // [0] JointLimits, [1] VelocityLimits: pg_pz_pz = pq_pz_pz / pq_d_pz_pz = zero matrices (JointLimits.cpp:40-44)
+        // [2] TorqueLimits: pg_pz_pz(i * Nact + j) = ptau_pz_pz(j, i)  (TorqueLimits.cpp:36-40)
+        bool any = false;
+        for (int r = p.offsets[2]; r < p.offsets[3]; r++) any = any || (lam[r] != 0);  // :568-578
+        if (any) {
+            idh.compute(p.id, z);
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < Nact; j++) hessian = hessian + idh.ptau_pz_pz[i][j] * lam[p.offsets[2] + i * Nact + j];  // :616
+        }
+        // [3] KinovaCustomizedConstraints
+        any = false;
+        for (int r = p.offsets[3]; r < p.offsets[4]; r++) any = any || (lam[r] != 0);
+        if (any && kc->box.numObstacles > 0) {  // KinovaCustomizedConstraints.cpp:80-82: pg_pz_pz keeps its zero initialisation
+            p.traj.compute(z, true);
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < kc->num_spheres; j++) {
+                    const double l = lam[p.offsets[3] + i * kc->num_spheres + j];
+                    hessian = hessian + kinova_sphere_hessian(*kc, i, j) * l;
+                }
+        }
+        size_t it = (size_t)b * (n * (n + 1) / 2);
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) H[it++] = hessian(i, j);  // :621-627
+    }
+    ORACLE_CATCH
+}
+int oracle_eval_h_batch(raptor_problem* pr, const double* Z, int B, const double* obj_factor, const double* lambda, double* H, void*) {
+    return oracle_eval_h_batch_host(pr, Z, B, obj_factor, lambda, H);
+}
+
+// oracle-only component view: InverseDynamics::ptau_pz_pz (InverseDynamics.cpp:141-171), [B][N][nv][n][n] -- what the reference's
+// Hessian test reads (Tests/KinematicsDynamics/TestInverseDynamics.cpp:48-79)
+int oracle_inverse_dynamics_hessian_host(raptor_problem* pr, const double* Z, int B, double* ptau_pz_pz) {
+    ORACLE_TRY
+    if (!pr || !Z || !ptau_pz_pz) throw std::invalid_argument("null argument");
+    Problem& p = pr->p;
+    const int nv = p.model.nv, N = p.traj.N, n = p.n;
+    InverseDynamicsHessian idh;
+    for (int b = 0; b < B; b++) {
+        idh.compute(p.id, Z + (size_t)b * n);
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < nv; j++)
+                for (int x = 0; x < n; x++)
+                    for (int y = 0; y < n; y++)
+                        ptau_pz_pz[((((size_t)b * N + i) * nv + j) * n + x) * n + y] = idh.ptau_pz_pz[i][j](x, y);
+    }
+    ORACLE_CATCH
 }
 
 int oracle_trajectory_eval_host(raptor_problem* pr, const double* Z, int B, double* q, double* q_d, double* q_dd) {

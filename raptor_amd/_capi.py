@@ -222,6 +222,7 @@ EXPORTS = [
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
     "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host", "step_link_eval_batch", "step_link_eval_batch_host",
+    "kinova_set_objective", "kinova_eval_objective", "kinova_eval_objective_host", "eval_h_batch", "eval_h_batch_host",
 ]
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
 DEVICE_ONLY_EXPORTS = ["probe_fill"]
@@ -263,6 +264,13 @@ class CApi:
         f("dual_kinova_arm_arm_batch_host").argtypes = [vp, vp, _dp, C.c_int, C.c_uint, _dp, _dp]
         f("step_link_eval_batch").argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint, vp, vp, vp, vp]
         f("step_link_eval_batch_host").argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_uint, _dp, _dp, _dp]
+        f("kinova_set_objective").argtypes = [vp, _dp, C.c_int]
+        f("kinova_eval_objective").argtypes = [vp, vp, C.c_int, vp, vp, vp]
+        f("kinova_eval_objective_host").argtypes = [vp, _dp, C.c_int, _dp, _dp]
+        f("eval_h_batch").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+        f("eval_h_batch_host").argtypes = [vp, _dp, C.c_int, _dp, _dp, _dp]
+        if prefix == "oracle_":
+            f("inverse_dynamics_hessian_host").argtypes = [vp, _dp, C.c_int, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         if prefix == "raptor_":
@@ -521,6 +529,41 @@ class ProblemHandle:
         J = np.empty((B, self.m, self.n)) if flags & EVAL_JAC else None
         self.api.check(self.api.fn("eval_batch_host")(self.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J)))
         return G, J
+
+    # -- KinovaOptimizer objective and Optimizer::eval_h -------------------------------------
+    def set_objective(self, q_des, tplan_n: int) -> None:
+        q = _f64(q_des)
+        self.api.check(self.api.fn("kinova_set_objective")(self.handle, _ptr(q), int(tplan_n)))
+
+    def objective_host(self, Z, derivatives: bool = True):
+        """KinovaOptimizer::eval_f / eval_grad_f: f [B], grad_f [B][n]."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        F = np.empty(B)
+        GR = np.empty((B, self.n)) if derivatives else None
+        self.api.check(self.api.fn("kinova_eval_objective_host")(self.handle, _ptr(Z), B, _ptr(F), _ptr(GR)))
+        return F, GR
+
+    def eval_h_host(self, Z, lam, obj_factor=None):
+        """Optimizer::eval_h: upper triangle (row by row) of obj_factor * hess_f + sum_r lambda_r * pg_pz_pz(r), [B][n(n+1)/2]."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        lam = _f64(lam).reshape(B, self.m)
+        of = None if obj_factor is None else _f64(np.broadcast_to(obj_factor, (B,)))
+        H = np.empty((B, self.n * (self.n + 1) // 2))
+        self.api.check(self.api.fn("eval_h_batch_host")(self.handle, _ptr(Z), B, _ptr(of), _ptr(lam), _ptr(H)))
+        return H
+
+    def eval_h_device(self, d_Z: int, B: int, d_obj_factor: int, d_lambda: int, d_H: int, stream: int = 0) -> None:
+        self.api.check(self.api.fn("eval_h_batch")(self.handle, d_Z, B, d_obj_factor or None, d_lambda, d_H, stream or None))
+
+    def inverse_dynamics_hessian_host(self, Z, N: int, nv: int):
+        """Oracle only: InverseDynamics::ptau_pz_pz [B][N][nv][n][n]."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        H = np.empty((B, N, nv, self.n, self.n))
+        self.api.check(self.api.fn("inverse_dynamics_hessian_host")(self.handle, _ptr(Z), B, _ptr(H)))
+        return H
 
     def eval_device(self, d_Z: int, B: int, flags: int, d_G: int, d_JAC: int, stream: int = 0) -> None:
         """Raw device pointers (ints), asynchronous on ``stream``."""

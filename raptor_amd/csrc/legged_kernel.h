@@ -46,6 +46,12 @@ struct LegLds {
 
 // Utils::wrapToPi (Utils/include/Utils.h:59-68)
 RD double wrap_to_pi(double a) {
+    // the reference's loops, bounded so that every wave finishes: beyond 64 turns one remainder step comes first, and a
+    // non-finite angle (the reference would never return) is handed back as it is
+    if (!(fabs(a) <= 128.0 * M_PI)) {
+        if (!isfinite(a)) return a;
+        a = remainder(a, 2.0 * M_PI);
+    }
     while (a > M_PI) a -= 2.0 * M_PI;
     while (a < -M_PI) a += 2.0 * M_PI;
     return a;

@@ -20,6 +20,7 @@
 #include "legged_kernel.h"
 #include "digit_kernel.h"
 #include "period_kernel.h"
+#include "kinova_hess_kernel.h"
 #include "digit_constants.h"
 #include "digit_tables.h"
 
@@ -124,6 +125,8 @@ struct raptor_problem {
     DevBuf<double> d_basis, d_wsum;
     DevBuf<DevSpheres> d_spheres;
     DevBuf<DevBox> d_boxes;
+    DevBuf<double> d_qdes;  // KinovaOptimizer::q_des, tplan_n (raptor_kinova_set_objective); tplan_n < 0: not set
+    int tplan_n = -1;
     // staging for the *_host entry points (grown on demand, reused)
     DevBuf<double> s_Z, s_G, s_J, s_a, s_b, s_c;
     // optional per-kernel HIP-event timing (raptor_profile_begin / _end)
@@ -1389,6 +1392,80 @@ int raptor_eval_costs_host(raptor_problem* p, const double* Z, int B, int num_co
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(F, p->s_G.p, (size_t)B * num_costs * sizeof(double), hipMemcpyDeviceToHost));
     if (GRAD) HIP_CHECK(hipMemcpy(GRAD, p->s_J.p, (size_t)B * num_costs * n * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_kinova_set_objective(raptor_problem* p, const double* q_des, int tplan_n) {
+    API_TRY
+    if (!p || !q_des) throw std::invalid_argument("null argument");
+    if (p->kind != 1) throw std::invalid_argument("objective: not a KinovaOptimizer problem");
+    if (tplan_n < 0 || tplan_n >= p->htraj.N) throw std::invalid_argument("tplan_n must be in [0, N)");
+    p->d_qdes.upload(q_des, 7);
+    p->tplan_n = tplan_n;
+    API_CATCH
+}
+
+int raptor_kinova_eval_objective(raptor_problem* p, const double* d_Z, int B, double* d_F, double* d_GRAD, void* stream) {
+    API_TRY
+    if (!p || (B > 0 && (!d_Z || !d_F))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (p->kind != 1 || p->tplan_n < 0) throw std::invalid_argument("objective: raptor_kinova_set_objective has not been called");
+    if (B == 0) return RAPTOR_OK;
+    hipLaunchKernelGGL(kinova_objective_kernel, dim3(grid_for(B)), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, p->d_traj.p,
+                       p->d_basis.p, p->d_wsum.p, d_Z, p->d_qdes.p, p->tplan_n, B, d_F, d_GRAD);
+    HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+int raptor_kinova_eval_objective_host(raptor_problem* p, const double* Z, int B, double* F, double* GRAD) {
+    API_TRY
+    if (!p || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (p->kind != 1 || p->tplan_n < 0) throw std::invalid_argument("objective: raptor_kinova_set_objective has not been called");
+    if (B == 0) return RAPTOR_OK;
+    p->s_Z.upload(Z, (size_t)B * 7);
+    p->s_a.ensure(B);
+    if (GRAD) p->s_b.ensure((size_t)B * 7);
+    const int rc = raptor_kinova_eval_objective(p, p->s_Z.p, B, p->s_a.p, GRAD ? p->s_b.p : nullptr, nullptr);
+    if (rc != RAPTOR_OK) return rc;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(F, p->s_a.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
+    if (GRAD) HIP_CHECK(hipMemcpy(GRAD, p->s_b.p, (size_t)B * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const double* d_obj_factor, const double* d_lambda, double* d_H,
+                        void* stream) {
+    API_TRY
+    if (!p || (B > 0 && (!d_Z || !d_lambda || !d_H))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (p->kind != 1) throw std::runtime_error("eval_h: enable_hessian is false for this optimizer");  // Optimizer.cpp:513-515
+    if (d_obj_factor && p->tplan_n < 0) throw std::invalid_argument("eval_h: raptor_kinova_set_objective has not been called");
+    if (B == 0) return RAPTOR_OK;
+    if (!p->hmodel.serial_chain) throw unsupported_error("eval_h kernel: serial-chain models only");
+    for (int l = 0; l < p->hmodel.nv; l++)
+        if (std::abs(p->hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
+    hipLaunchKernelGGL(kinova_hessian_kernel, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, p->d_model.p, p->d_traj.p,
+                       p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda,
+                       p->tplan_n < 0 ? 0 : p->tplan_n, d_H);
+    HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+int raptor_eval_h_batch_host(raptor_problem* p, const double* Z, int B, const double* obj_factor, const double* lambda, double* H) {
+    API_TRY
+    if (!p || (B > 0 && (!Z || !lambda || !H))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    const size_t n = p->layout.n, m = p->layout.m, nh = n * (n + 1) / 2;
+    p->s_Z.upload(Z, (size_t)B * n);
+    p->s_G.upload(lambda, (size_t)B * m);
+    if (obj_factor) p->s_a.upload(obj_factor, B);
+    p->s_b.ensure((size_t)B * nh);
+    const int rc = raptor_eval_h_batch(p, p->s_Z.p, B, obj_factor ? p->s_a.p : nullptr, p->s_G.p, p->s_b.p, nullptr);
+    if (rc != RAPTOR_OK) return rc;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(H, p->s_b.p, (size_t)B * nh * sizeof(double), hipMemcpyDeviceToHost));
     API_CATCH
 }
 

@@ -1,0 +1,120 @@
+"""Pins the oracle's second-order path (KinovaOptimizer eval_h: SURVEY.md 8f row 1) before it checks the GPU.
+
+The reference holds no golden vector for it; what it holds is a recipe:
+  * Tests/KinematicsDynamics/TestInverseDynamics.cpp:48-79 -- ptau_pz_pz(j, i) against central differences of
+    ptau_pz(i).row(j), Polynomials(2.0, 10, nv, Uniform, 3), tolerance 1e-5 (checked there for j = 6 only, here all j);
+  * Tests/Constraints/TestBoxCollisionAvoidance.cpp:76-123 -- box-distance Hessian against differences of the gradient.
+Both run here on the oracle, plus the whole Lagrangian Hessian against differences of lambda^T pg_pz.
+"""
+import numpy as np
+import pytest
+
+from raptor_amd import _capi as A
+
+import helpers as H
+
+
+def unpack_upper(h, n):
+    M = np.zeros((n, n))
+    it = 0
+    for i in range(n):
+        for j in range(i, n):
+            M[i, j] = M[j, i] = h[it]
+            it += 1
+    return M
+
+
+def test_inverse_dynamics_hessian_like_reference(oracle, kinova_friction):
+    keep = []
+    p = H.id_problem(oracle, kinova_friction, keep, disc=A.TIME_UNIFORM, N=4)
+    rng = np.random.default_rng(12)
+    z = (2 / np.pi) * rng.uniform(-1, 1, p.n)  # M_2_PI * Random
+    Hs = p.inverse_dynamics_hessian_host(z, 4, 7)[0]  # [N][nv][n][n]
+    assert np.abs(Hs - np.swapaxes(Hs, -1, -2)).max() < 1e-10
+    h = 1e-6
+    for j in range(p.n):
+        e = np.zeros(p.n)
+        e[j] = h
+        _, Jp = p.inverse_dynamics_host(z + e, 4, 7)
+        _, Jm = p.inverse_dynamics_host(z - e, 4, 7)
+        num = (Jp - Jm)[0] / (2 * h)  # [N][nv][n]: d ptau_pz(i)(k, :) / dz_j
+        for i in range(4):
+            for k in range(7):
+                assert np.linalg.norm(Hs[i, k, j, :] - num[i, k, :]) < 1e-5
+
+
+def test_objective_like_reference(oracle, kinova):
+    """KinovaOptimizer::eval_f / eval_grad_f / eval_hess_f (KinovaOptimizer.cpp:152-250)."""
+    keep = []
+    p = H.kinova_problem(oracle, kinova, keep, N=8)
+    rng = np.random.default_rng(3)
+    q_des = rng.uniform(-4, 4, 7)  # beyond pi: the continuous joints wrap
+    with pytest.raises(A.RaptorInvalidArgument):
+        p.objective_host(np.zeros(7))
+    with pytest.raises(A.RaptorInvalidArgument):
+        p.set_objective(q_des, 8)
+    p.set_objective(q_des, 5)
+    Z = rng.uniform(-1, 1, (3, 7))
+    F, GR = p.objective_host(Z)
+    q, _, _ = p.trajectory_host(Z, 8, 7)
+    d = q[:, 5, :] - q_des
+    d[:, 0::2] = (d[:, 0::2] + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(F - 0.5 * (d ** 2).sum(axis=1)).max() < 1e-13
+    h = 1e-6
+    for j in range(7):
+        e = np.zeros(7)
+        e[j] = h
+        num = (p.objective_host(Z + e, False)[0] - p.objective_host(Z - e, False)[0]) / (2 * h)
+        assert np.abs(num - GR[:, j]).max() < 1e-7
+    # hess_f alone: lambda = 0, obj_factor = 2
+    Hh = p.eval_h_host(Z, np.zeros((3, p.m)), 2.0)
+    _, J = p.eval_host(Z[:1], A.EVAL_JAC)
+    s = J[0, 5 * 7, 0]  # pq_pz(tplan_n)(0, 0)
+    for b in range(3):
+        assert np.abs(unpack_upper(Hh[b], 7) - 2.0 * s * s * np.eye(7)).max() < 1e-14
+
+
+@pytest.mark.parametrize("gripper", [False, True])
+def test_lagrangian_hessian_fd(oracle, kinova, gripper):
+    """Optimizer::eval_h against central differences of lambda^T pg_pz (the reference's derivative_test, second order)."""
+    keep = []
+    p = H.kinova_problem(oracle, kinova, keep, N=6, boxes=H.reach_boxes(), gripper=gripper)
+    rng = np.random.default_rng(21 + gripper)
+    z = rng.uniform(-1, 1, 7)
+    lam = rng.uniform(-1, 1, p.m)
+    Hh = unpack_upper(p.eval_h_host(z, lam)[0], 7)
+    h = 1e-6
+    num = np.zeros((7, 7))
+    for j in range(7):
+        e = np.zeros(7)
+        e[j] = h
+        _, Jp = p.eval_host(z + e, A.EVAL_JAC)
+        _, Jm = p.eval_host(z - e, A.EVAL_JAC)
+        num[j] = lam @ (Jp[0] - Jm[0]) / (2 * h)
+    # obstacle rows are only piecewise smooth; with 6 x 17 of them a kink inside a stencil is possible but not for this seed
+    assert np.abs(Hh - num).max() < 1e-5 * max(1.0, np.abs(Hh).max()), (np.abs(Hh - num).max(), np.abs(Hh).max())
+    # each block alone, by zeroing the other multipliers (Optimizer.cpp:566-578 skips all-zero blocks)
+    off = p.block_offsets
+    parts = np.zeros((7, 7))
+    for blk in range(4):
+        l2 = np.zeros(p.m)
+        l2[off[blk]:off[blk + 1]] = lam[off[blk]:off[blk + 1]]
+        Hb = unpack_upper(p.eval_h_host(z, l2)[0], 7)
+        if blk < 2:
+            assert np.all(Hb == 0.0)  # JointLimits / VelocityLimits: linear in z
+        parts += Hb
+    assert np.abs(parts - Hh).max() < 1e-12 * max(1.0, np.abs(Hh).max())
+
+
+def test_no_obstacles_and_errors(oracle, kinova):
+    keep = []
+    none = (np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)))
+    p = H.kinova_problem(oracle, kinova, keep, N=4, boxes=none)
+    lam = np.zeros(p.m)
+    lam[p.block_offsets[3]:] = 1.0
+    assert np.all(p.eval_h_host(np.zeros(7), lam) == 0.0)  # KinovaCustomizedConstraints.cpp:80-82
+    with pytest.raises(A.RaptorInvalidArgument):
+        p.eval_h_host(np.zeros(7), lam, 1.0)  # objective not set
+    pid = H.id_problem(oracle, kinova, keep)
+    with pytest.raises(A.RaptorError):
+        pid.eval_h_host(np.zeros(pid.n), np.zeros(pid.m))  # enable_hessian is false (Optimizer.cpp:513-515)
