@@ -118,6 +118,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Digit record appended to the default (Kinova) line")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loop (profiling runs: keeps the kernel statistics to the batch launches)")
+    ap.add_argument("--no-eval-h", action="store_true", help="skip the eval_h record of the Kinova line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -246,7 +247,60 @@ def main() -> None:
             out["single_problem_eval_jac_g_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
         if world == 1 and cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), cpu_seconds, G, J)
+        if W.name == "kinova" and world == 1 and not args.no_eval_h:
+            out["eval_h"] = eval_h_record(W, prob, Z, B, cpu_seconds > 0)
         return out
+
+    def eval_h_record(W, prob, Z, B, with_cpu):
+        """Optimizer::eval_h for the same batch (KinovaOptimizer runs with exact Hessians): one fused kernel per call,
+        28 doubles out per z.  Timed with events on the evaluation stream; checked against the oracle on the first z."""
+        import numpy as np
+
+        prob.set_objective(np.zeros(prob.n), W.samples // 2)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        lam = (torch.rand(B, prob.m, generator=gen, dtype=torch.float64) * 2 - 1).cuda()
+        of = torch.ones(B, dtype=torch.float64, device="cuda")
+        Hh = torch.empty(B, prob.n * (prob.n + 1) // 2, dtype=torch.float64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def call():
+            prob.eval_h_device(Z.data_ptr(), B, of.data_ptr(), lam.data_ptr(), Hh.data_ptr(), stream)
+
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rec = {
+            "kernel": "kinova_hessian_kernel (hyper-dual forward recursion, Lagrangian Hessian fused)",
+            "ms_per_call": ms,
+            "lagrangian_hessians_per_s": B / (ms * 1e-3),
+            "sample_evals_per_s": B * W.samples / (ms * 1e-3),
+            "batch": B, "samples": W.samples,
+        }
+        if with_cpu:
+            import helpers as H
+
+            oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
+            keep2 = []
+            po = W.build(oracle, keep2)
+            po.set_objective(np.zeros(prob.n), W.samples // 2)
+            nz = 8
+            t0 = time.perf_counter()
+            Ho = po.eval_h_host(Z[:nz].cpu().numpy(), lam[:nz].cpu().numpy(), 1.0)
+            dt = time.perf_counter() - t0
+            err = H.rel_err(Hh[:nz].cpu().numpy(), Ho)
+            if not err < 1e-9:
+                raise SystemExit(f"GPU eval_h differs from the oracle: {err:.2e}")
+            rec["cpu_oracle_ms_per_z"] = 1e3 * dt / nz
+            rec["rel_err_vs_oracle"] = err
+        return rec
 
     out = run(WORKLOADS[args.workload](), args.batch, 0.0 if args.no_cpu_baseline else args.cpu_seconds)
     if args.workload == "kinova" and not args.no_secondary:
