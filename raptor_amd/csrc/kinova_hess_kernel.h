@@ -10,297 +10,387 @@
 //     (virtual power), so phi needs only the FORWARD recursion of RNEA: v_l, a_l, w_l, f_l = I a + v x* I v.
 //     pinocchio::ComputeRNEASecondOrderDerivatives' four nv^3 tensors and the dense products of
 //     InverseDynamics.cpp:141-171 are never formed;
-//   * second derivatives by hyper-dual numbers: a lane owns one pair (a <= b) of decision variables and carries
-//     (value, d/dz_a, d/dz_b, d2/dz_a dz_b) of v, a, w through the 7 links in link-local frames (constant inertias).
-//     ArmourBezierCurves is linear in z with a diagonal pq_pz (ArmourBezierCurves.cpp:147-151), so the seeds are
-//     (pq_pz, pq_d_pz, pq_dd_pz)(k, k) on joint k = a and k = b;  damping, friction and armature terms are linear: no Hessian;
-//   * 32 lanes per sample (28 pairs), 8 samples per workgroup pass, one workgroup per decision vector: the sum over the
-//     N samples stays in registers, the 8 partial sums meet in LDS in a fixed order (deterministic, no atomics);
-//   * obstacle rows (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:206-288, 451-474): lanes 0..ns-1 find
-//     their sphere's arg-min box (same code and tie rules as the Jacobian kernel) and publish the distance's gradient n and
-//     3 x 3 Hessian K = sign/d (P - n n^T) w.r.t. the sphere centre, P = the reference's clamped-axis projector; a pair lane
-//     then adds  lambda s^2 (J_a^T K J_b + n . H_ab),  J_c = w_c x (p - o_c),  H_ab = w_a x J_b  (a <= b): the FK Hessian of
-//     ForwardKinematics.cpp:386-402 in closed form from the world-frame joint axes.
+//   * second derivatives by hyper-dual numbers (value, d/dz_a, d/dz_b, d2/dz_a dz_b) carried through the links in
+//     link-local frames (constant inertias).  ArmourBezierCurves is linear in z with a diagonal pq_pz
+//     (ArmourBezierCurves.cpp:147-151): the seeds are (pq_pz, pq_d_pz, pq_dd_pz)(k, k) on joint k = a and k = b; damping,
+//     friction and armature are linear in (q_d, q_dd): no Hessian;
+//   * a WAVEFRONT owns one pair (a <= b), its 64 lanes are 64 time samples.  The pair being wave-uniform, the chain is walked
+//     in three regimes with scalar branches: links below a carry plain values, links a .. b-1 first-order duals in z_a,
+//     links b .. 6 full hyper-duals -- and only those contribute to d2 phi / dz_a dz_b, so forces are formed from link b on.
+//     Past its seeded link a regime multiplies by plain sines / cosines.  84 of the 196 (pair, link) steps are hyper-dual;
+//   * one workgroup (4 wavefronts) per decision vector, 64 samples per pass: trajectory values and sincos once per (sample,
+//     joint) into LDS (sample-minor: conflict-free), the 28 pairs dealt 7 per wavefront by cost; the sum over samples is a
+//     wave reduction, the sum over passes stays with the owning wavefront: deterministic, no atomics;
+//   * obstacle rows (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:206-288, 451-474): a wavefront owns
+//     one sphere (its joint is wave-uniform), lanes = samples: arg-min box with the Jacobian kernel's code and tie rules, the
+//     distance's gradient n and Hessian K = sign/d (P - n n^T) w.r.t. the centre (P = the reference's clamped-axis projector),
+//     then  lambda s^2 (J_a^T K J_b + n . H_ab),  J_c = w_c x (p - o_c),  H_ab = w_a x J_b  (a <= b): the FK Hessian of
+//     ForwardKinematics.cpp:386-402 in closed form from the world-frame joint axes of that sample.
 #ifndef RAPTOR_KINOVA_HESS_KERNEL_H
 #define RAPTOR_KINOVA_HESS_KERNEL_H
 
 #include "kinova_kernel.h"
 #include "legged_kernel.h"  // wrap_to_pi
 
-#define HG 32        // lanes per sample
-#define H_GROUPS 8   // samples in flight per 256-lane workgroup
+#define H_CH 64      // samples per pass = lanes of a wavefront
 #define H_PAIRS 28   // 7 * 8 / 2
-// LDS layout per group, in doubles
-#define HL_X 0       // per joint: q_d, q_dd, cos q, sin q, q        7 x 5
-#define HL_W 36      // per joint: world axis (3), world origin (3)  7 x 6
-#define HL_RO 78     // R, o of up to 4 sphere-carrying links        4 x 12
-#define HL_MU 126    // multipliers of the sample's torque rows      7
-#define HL_SP 134    // per sphere: centre (3), n' (3), K' (6), joint id (1), pad
-#define HL_SPW 14
-#define HL_STRIDE (HL_SP + RAPTOR_MAX_SPHERES * HL_SPW)
+#define H_WAVES 4
+// LDS (doubles), every table sample-minor: [field][64]
+#define HL_X 0                        // per joint: q_d, q_dd, cos q, sin q, q        35 x 64
+#define HL_MU (35 * H_CH)             // multipliers of the torque rows               7 x 64
+#define HL_WS (HL_MU + 7 * H_CH)      // pq_pz, pq_d_pz, pq_dd_pz diagonal            3 x 64
+#define HL_W (HL_WS + 3 * H_CH)       // per joint: world axis (3), world origin (3)  42 x 64
+#define HL_RO (HL_W + 42 * H_CH)      // R, o of up to 4 sphere-carrying links        48 x 64
+#define HL_ACC (HL_RO + 48 * H_CH)    // per wavefront: 28 obstacle partial sums, then 28 torque sums
+#define HL_TOTAL (HL_ACC + 2 * H_WAVES * H_PAIRS)
 
-// hyper-dual number: value, two first-order parts, the mixed second-order part
+// first-order dual and hyper-dual numbers
+struct D1 {
+    double v, a;
+};
 struct HD {
     double v, a, b, ab;
 };
-RD HD hd(double v) { return HD{v, 0.0, 0.0, 0.0}; }
+RD D1 operator+(D1 x, D1 y) { return D1{x.v + y.v, x.a + y.a}; }
+RD D1 operator-(D1 x, D1 y) { return D1{x.v - y.v, x.a - y.a}; }
+RD D1 operator*(D1 x, D1 y) { return D1{x.v * y.v, x.a * y.v + x.v * y.a}; }
+RD D1 operator*(double s, D1 x) { return D1{s * x.v, s * x.a}; }
+RD D1 operator*(D1 x, double s) { return D1{s * x.v, s * x.a}; }
+RD D1 operator+(D1 x, double y) { return D1{x.v + y, x.a}; }
 RD HD operator+(HD x, HD y) { return HD{x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
 RD HD operator-(HD x, HD y) { return HD{x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
-RD HD operator-(HD x) { return HD{-x.v, -x.a, -x.b, -x.ab}; }
 RD HD operator*(HD x, HD y) {
     return HD{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
 }
 RD HD operator*(double s, HD x) { return HD{s * x.v, s * x.a, s * x.b, s * x.ab}; }
 RD HD operator*(HD x, double s) { return HD{s * x.v, s * x.a, s * x.b, s * x.ab}; }
-struct H3 {
-    HD c[3];
+RD HD operator+(HD x, double y) { return HD{x.v + y, x.a, x.b, x.ab}; }
+RD void add_value(double& x, double y) { x += y; }
+RD void add_value(D1& x, double y) { x.v += y; }
+RD void add_value(HD& x, double y) { x.v += y; }
+RD D1 promote(double x, D1*) { return D1{x, 0.0}; }
+RD HD promote(D1 x, HD*) { return HD{x.v, x.a, 0.0, 0.0}; }
+RD HD promote(double x, HD*) { return HD{x, 0.0, 0.0, 0.0}; }
+
+template <class S>
+struct T3 {
+    S c[3];  // compile-time indices only
 };
-RD H3 operator+(const H3& x, const H3& y) { return H3{{x.c[0] + y.c[0], x.c[1] + y.c[1], x.c[2] + y.c[2]}}; }
-RD H3 cross(const H3& x, const H3& y) {
-    return H3{{x.c[1] * y.c[2] - x.c[2] * y.c[1], x.c[2] * y.c[0] - x.c[0] * y.c[2], x.c[0] * y.c[1] - x.c[1] * y.c[0]}};
+template <class S>
+RD T3<S> operator+(const T3<S>& x, const T3<S>& y) { return T3<S>{{x.c[0] + y.c[0], x.c[1] + y.c[1], x.c[2] + y.c[2]}}; }
+template <class S>
+RD T3<S> cross(const T3<S>& x, const T3<S>& y) {
+    return T3<S>{{x.c[1] * y.c[2] - x.c[2] * y.c[1], x.c[2] * y.c[0] - x.c[0] * y.c[2], x.c[0] * y.c[1] - x.c[1] * y.c[0]}};
 }
-// constant vector x hyper-dual vector
-RD H3 cross(V3 p, const H3& y) {
-    return H3{{p.y * y.c[2] - p.z * y.c[1], p.z * y.c[0] - p.x * y.c[2], p.x * y.c[1] - p.y * y.c[0]}};
+template <class S>
+RD T3<S> cross(V3 p, const T3<S>& y) {  // constant x state
+    return T3<S>{{p.y * y.c[2] - p.z * y.c[1], p.z * y.c[0] - p.x * y.c[2], p.x * y.c[1] - p.y * y.c[0]}};
 }
-RD H3 cross(const H3& x, V3 p) {
-    return H3{{x.c[1] * p.z - x.c[2] * p.y, x.c[2] * p.x - x.c[0] * p.z, x.c[0] * p.y - x.c[1] * p.x}};
+template <class S>
+RD T3<S> cross(const T3<S>& x, V3 p) {
+    return T3<S>{{x.c[1] * p.z - x.c[2] * p.y, x.c[2] * p.x - x.c[0] * p.z, x.c[0] * p.y - x.c[1] * p.x}};
 }
-// R^T x for a constant row-major 3 x 3 R
-RD H3 mulT(const double* R, const H3& x) {
-    return H3{{R[0] * x.c[0] + R[3] * x.c[1] + R[6] * x.c[2], R[1] * x.c[0] + R[4] * x.c[1] + R[7] * x.c[2],
-               R[2] * x.c[0] + R[5] * x.c[1] + R[8] * x.c[2]}};
+template <class S>
+RD T3<S> mulT(const double* R, const T3<S>& x) {  // R^T x, constant row-major R
+    return T3<S>{{R[0] * x.c[0] + R[3] * x.c[1] + R[6] * x.c[2], R[1] * x.c[0] + R[4] * x.c[1] + R[7] * x.c[2],
+                  R[2] * x.c[0] + R[5] * x.c[1] + R[8] * x.c[2]}};
 }
-RD H3 symmul(const double* Ic, const H3& x) {  // (xx, xy, xz, yy, yz, zz)
-    return H3{{Ic[0] * x.c[0] + Ic[1] * x.c[1] + Ic[2] * x.c[2], Ic[1] * x.c[0] + Ic[3] * x.c[1] + Ic[4] * x.c[2],
-               Ic[2] * x.c[0] + Ic[4] * x.c[1] + Ic[5] * x.c[2]}};
+template <class S>
+RD T3<S> symmul(const double* Ic, const T3<S>& x) {  // (xx, xy, xz, yy, yz, zz)
+    return T3<S>{{Ic[0] * x.c[0] + Ic[1] * x.c[1] + Ic[2] * x.c[2], Ic[1] * x.c[0] + Ic[3] * x.c[1] + Ic[4] * x.c[2],
+                  Ic[2] * x.c[0] + Ic[4] * x.c[1] + Ic[5] * x.c[2]}};
 }
-// the mixed part of x . y
-RD double dot_ab(const H3& x, const H3& y) {
+RD double dot_ab(const T3<HD>& x, const T3<HD>& y) {  // the mixed part of x . y
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) s += x.c[k].v * y.c[k].ab + x.c[k].a * y.c[k].b + x.c[k].b * y.c[k].a + x.c[k].ab * y.c[k].v;
     return s;
 }
 
-// Joint about local axis K (Spatial.h:115-258 jcalc, Xup = XJ * Xtree): rotate the parent's motion vectors into the link
-// frame, add the joint's own motion S = sg e_K.   C = cos(theta), Sn = sin(theta), theta = sg q.
-template <int K>
-RD void hess_joint(HD C, HD Sn, double sg, HD qd, HD qdd, double mu, H3& va, H3& vl, H3& aa, H3& al, H3& wa, H3& wl) {
-    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
-#define HROT(x) { const HD xi_ = C * x.c[I] + Sn * x.c[J]; const HD xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
-    HROT(va) HROT(vl) HROT(aa) HROT(al) HROT(wa) HROT(wl)
-#undef HROT
-    const HD vj = sg * qd;
-    va.c[K] = va.c[K] + vj;  // v_l = Xup v_parent + S q_d                 (CustomizedInverseDynamics.cpp:155)
-    // a_l = Xup a_parent + crm(v_l) (S q_d) + S q_dd                        (:157)
-    aa.c[I] = aa.c[I] + va.c[J] * vj;
-    aa.c[J] = aa.c[J] - va.c[I] * vj;
-    al.c[I] = al.c[I] + vl.c[J] * vj;
-    al.c[J] = al.c[J] - vl.c[I] * vj;
-    aa.c[K] = aa.c[K] + sg * qdd;
-    wa.c[K].v += sg * mu;    // virtual velocity under joint rates mu
+// spatial velocity, acceleration and virtual velocity of the link being walked, [angular; linear], link-local frame
+template <class S>
+struct Kin {
+    T3<S> va, vl, aa, al, wa, wl;
+};
+template <class S, class P>
+RD Kin<S> promote(const Kin<P>& k) {
+    Kin<S> r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        r.va.c[i] = promote(k.va.c[i], (S*)nullptr); r.vl.c[i] = promote(k.vl.c[i], (S*)nullptr);
+        r.aa.c[i] = promote(k.aa.c[i], (S*)nullptr); r.al.c[i] = promote(k.al.c[i], (S*)nullptr);
+        r.wa.c[i] = promote(k.wa.c[i], (S*)nullptr); r.wl.c[i] = promote(k.wl.c[i], (S*)nullptr);
+    }
+    return r;
 }
+
+// Joint about local axis K (Spatial.h:115-258 jcalc, Xup = XJ * Xtree): rotate the parent's motion vectors into the link
+// frame, add the joint's own motion S = sg e_K.  C = cos(theta), Sn = sin(theta), theta = sg q; Tq = double past the seeded link.
+template <int K, class S, class Tq>
+RD void hess_joint(Tq C, Tq Sn, double sg, Tq qd, Tq qdd, double mu, Kin<S>& k) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#define HROT(x) { const S xi_ = C * x.c[I] + Sn * x.c[J]; const S xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
+    HROT(k.va) HROT(k.vl) HROT(k.aa) HROT(k.al) HROT(k.wa) HROT(k.wl)
+#undef HROT
+    const Tq vj = sg * qd;
+    k.va.c[K] = k.va.c[K] + vj;  // v_l = Xup v_parent + S q_d                 (CustomizedInverseDynamics.cpp:155)
+    // a_l = Xup a_parent + crm(v_l) (S q_d) + S q_dd                            (:157)
+    k.aa.c[I] = k.aa.c[I] + k.va.c[J] * vj;
+    k.aa.c[J] = k.aa.c[J] - k.va.c[I] * vj;
+    k.al.c[I] = k.al.c[I] + k.vl.c[J] * vj;
+    k.al.c[J] = k.al.c[J] - k.vl.c[I] * vj;
+    k.aa.c[K] = k.aa.c[K] + sg * qdd;
+    add_value(k.wa.c[K], sg * mu);  // virtual velocity under joint rates mu
+}
+template <class S, class Tq>
+RD void hess_link(const DevModel* __restrict__ M, int l, Tq C, Tq Sn, Tq qd, Tq qdd, double mu, Kin<S>& k) {
+    // Xtree = plux(R^T, p): [w; v] -> [R^T w; R^T (v + w x p)]   (CustomizedInverseDynamics.cpp:43-47, Utils.h:185-191)
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+    k.vl = mulT(M->plR[l], k.vl + cross(k.va, p));
+    k.va = mulT(M->plR[l], k.va);
+    k.al = mulT(M->plR[l], k.al + cross(k.aa, p));
+    k.aa = mulT(M->plR[l], k.aa);
+    k.wl = mulT(M->plR[l], k.wl + cross(k.wa, p));
+    k.wa = mulT(M->plR[l], k.wa);
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    if (aj == 3) hess_joint<2>(C, Sn, sg, qd, qdd, mu, k);
+    else if (aj == 2) hess_joint<1>(C, Sn, sg, qd, qdd, mu, k);
+    else hess_joint<0>(C, Sn, sg, qd, qdd, mu, k);
+}
+// mixed part of w . f,  f = I a + v x* (I v),  I = (mass, lever, inertia about the COM) in the link frame (:244-246)
+RD double hess_power_ab(const DevModel* __restrict__ M, int l, const Kin<HD>& k) {
+    const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
+    const double mass = M->mass[l];
+    T3<HD> hl = k.vl + cross(k.va, c);  // momentum, linear part
+    T3<HD> gl = k.al + cross(k.aa, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        hl.c[i] = mass * hl.c[i];
+        gl.c[i] = mass * gl.c[i];
+    }
+    const T3<HD> ha = symmul(M->Ic[l], k.va) + cross(c, hl);
+    const T3<HD> fl = gl + cross(k.va, hl);
+    double s = dot_ab(k.wl, fl);
+    const T3<HD> fa = symmul(M->Ic[l], k.aa) + cross(c, gl) + cross(k.va, ha) + cross(k.vl, hl);
+    return s + dot_ab(k.wa, fa);
+}
+
+RD double wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// pairs dealt to the four wavefronts by cost (hyper-dual links (7 - b) dominate); entries = a * 8 + b
+__device__ const unsigned char H_PAIR_OF[H_WAVES][7] = {
+    {0 * 8 + 0, 1 * 8 + 3, 1 * 8 + 4, 0 * 8 + 5, 1 * 8 + 5, 2 * 8 + 6, 3 * 8 + 6},
+    {0 * 8 + 1, 0 * 8 + 3, 3 * 8 + 3, 2 * 8 + 4, 4 * 8 + 5, 5 * 8 + 5, 6 * 8 + 6},
+    {1 * 8 + 1, 2 * 8 + 2, 0 * 8 + 4, 3 * 8 + 4, 3 * 8 + 5, 0 * 8 + 6, 5 * 8 + 6},
+    {0 * 8 + 2, 1 * 8 + 2, 2 * 8 + 3, 4 * 8 + 4, 2 * 8 + 5, 1 * 8 + 6, 4 * 8 + 6}};
+RD int pair_index(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a); }  // upper triangle row by row (Optimizer.cpp:531-538)
 
 __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
     const double* __restrict__ Z, const double* __restrict__ obj_factor, const double* __restrict__ lambda, const int tplan_n,
     double* __restrict__ Hout) {
-    __shared__ double lds[H_GROUPS * HL_STRIDE + H_GROUPS * HG];
+    __shared__ double lds[HL_TOTAL];
     constexpr int NV = 7;
     const int tid = threadIdx.x;
-    const int t = tid & (HG - 1);
-    const int grp = tid >> 5;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long b = blockIdx.x;
     const int N = T->N;
     const int ns = S->num_spheres;
     const int O = S->num_obstacles;
     const double* z = Z + b * NV;
     const double* lam = lambda + b * (long long)L.m;
-    double* sl = lds + grp * HL_STRIDE;
-
-    // lane -> pair (pa <= pb), upper triangle row by row (Optimizer.cpp:531-538)
-    int pa = 0, pb = 0;
-    {
-        int rem = (t < H_PAIRS) ? t : H_PAIRS - 1;
-        while (rem >= NV - pa) {
-            rem -= NV - pa;
-            pa++;
-        }
-        pb = pa + rem;
-    }
-    const bool pair = t < H_PAIRS;
-    double acc = 0.0;
+    if (lane < 2 * H_PAIRS) lds[HL_ACC + wave * 2 * H_PAIRS + lane] = 0.0;
 
 #pragma unroll 1
-    for (int i = grp; i < N; i += H_GROUPS) {
-        const double w0 = wsum[i * 3], w1 = wsum[i * 3 + 1], w2 = wsum[i * 3 + 2];
-        // ---- phase 0: joint t's trajectory value, sincos, multiplier ----
-        if (t < NV) {
+    for (int i0 = 0; i0 < N; i0 += H_CH) {
+        // ---- pass set-up: trajectory values, sincos, multipliers, basis weights of the 64 samples ----
+        for (int idx = tid; idx < H_CH * NV; idx += RAPTOR_BLOCK) {
+            const int s = idx & (H_CH - 1), j = idx >> 6;
+            const int i = min(i0 + s, N - 1);
             double q, qd, qdd, sq, cq;
-            traj_joint(T, basis, z, i, t, q, qd, qdd);
+            traj_joint(T, basis, z, i, j, q, qd, qdd);
             sincos(q, &sq, &cq);
-            double* x = sl + HL_X + t * 5;
-            x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
-            sl[HL_MU + t] = lam[L.off_tau + i * NV + t];
+            double* x = lds + HL_X + (j * 5) * H_CH + s;
+            x[0] = qd; x[H_CH] = qdd; x[2 * H_CH] = cq; x[3 * H_CH] = sq; x[4 * H_CH] = q;
+            lds[HL_MU + j * H_CH + s] = (i0 + s < N) ? lam[L.off_tau + i * NV + j] : 0.0;
         }
-        wave_sync();
-        // ---- phase A: world-frame joint axes / origins (lane t stops at link t), poses of the sphere-carrying links ----
-        if (t < NV && O > 0) {
+        if (tid < 3 * H_CH) {
+            const int s = tid & (H_CH - 1), k = tid >> 6;
+            lds[HL_WS + k * H_CH + s] = wsum[min(i0 + s, N - 1) * 3 + k];
+        }
+        __syncthreads();
+        const bool live = (i0 + lane) < N;
+        const double w0 = lds[HL_WS + lane], w1 = lds[HL_WS + H_CH + lane], w2 = lds[HL_WS + 2 * H_CH + lane];
+
+        // ---- world-frame joint axes / origins and sphere-link poses of every sample (first wavefront, lane = sample) ----
+        if (wave == 0 && O > 0) {
             M3 Rw;
 #pragma unroll
             for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
             V3 ow = v3(0, 0, 0);
-            SV s = sv_zero();
 #pragma unroll 1
-            for (int l = 0; l <= t; l++) {
-                const double* x = sl + HL_X + l * 5;
+            for (int l = 0; l < NV; l++) {
+                const double* x = lds + HL_X + (l * 5) * H_CH + lane;
                 const M3 A = mul(Rw, M->plR[l]);
                 V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
                 M3 R;
-                joint_world(M->jtype[l], x[4], x[2], x[3], A, R, o, s);
+                SV s;
+                joint_world(M->jtype[l], x[4 * H_CH], x[2 * H_CH], x[3 * H_CH], A, R, o, s);
                 Rw = R;
                 ow = o;
-            }
-            double* wv = sl + HL_W + t * 6;
-            wv[0] = s.a.x; wv[1] = s.a.y; wv[2] = s.a.z;
-            wv[3] = ow.x; wv[4] = ow.y; wv[5] = ow.z;
-            const int slot = S->ro_slot[t];
-            if (slot >= 0) {
-                double* ro = sl + HL_RO + slot * 12;
+                double* wv = lds + HL_W + (l * 6) * H_CH + lane;
+                wv[0] = s.a.x; wv[H_CH] = s.a.y; wv[2 * H_CH] = s.a.z;
+                wv[3 * H_CH] = ow.x; wv[4 * H_CH] = ow.y; wv[5 * H_CH] = ow.z;
+                const int slot = S->ro_slot[l];
+                if (slot >= 0) {
+                    double* ro = lds + HL_RO + (slot * 12) * H_CH + lane;
 #pragma unroll
-                for (int k = 0; k < 9; k++) ro[k] = Rw.m[k];
-                ro[9] = ow.x; ro[10] = ow.y; ro[11] = ow.z;
+                    for (int k = 0; k < 9; k++) ro[k * H_CH] = Rw.m[k];
+                    ro[9 * H_CH] = ow.x; ro[10 * H_CH] = ow.y; ro[11 * H_CH] = ow.z;
+                }
             }
         }
-        wave_sync();
-        // ---- phase S: sphere t -> arg-min box, gradient and Hessian of the distance w.r.t. the centre, weighted ----
-        if (O > 0 && t < ns) {
-            const int jid = S->joint_id[t];
-            const double* ro = sl + HL_RO + S->ro_slot[jid - 1] * 12;
-            M3 R;
-#pragma unroll
-            for (int k = 0; k < 9; k++) R.m[k] = ro[k];
-            const V3 point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[t][0], S->offset[t][1], S->offset[t][2]));
-            BoxBest best;
-            best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
-            for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
-            double* sp = sl + HL_SP + t * HL_SPW;
-            sp[0] = point.x; sp[1] = point.y; sp[2] = point.z;
-            const double wgt = lam[L.off_obs + i * ns + t] * w0 * w0;
-            if (best.d2 > 1e-12) {  // SQUARE_ROOT_THRESHOLD, BoxCollisionAvoidance.cpp:458
-                const DevBox* bx = boxes + best.idx;
-                M3 Rb;
-#pragma unroll
-                for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
-                const double inv = 1.0 / sqrt(best.d2);
-                const V3 nh = mul(Rb, best.dl) * inv;  // diff / |diff| in the world frame
-                const double ws = wgt * best.sign;
-                sp[3] = ws * nh.x; sp[4] = ws * nh.y; sp[5] = ws * nh.z;
-                // P = sum over the clamped axes (dl != 0 exactly there: :233-250, :269-273) of r_k r_k^T
-                const double c0 = (best.dl.x != 0.0) ? 1.0 : 0.0, c1 = (best.dl.y != 0.0) ? 1.0 : 0.0, c2 = (best.dl.z != 0.0) ? 1.0 : 0.0;
-                const V3 r0 = col(Rb, 0), r1 = col(Rb, 1), r2 = col(Rb, 2);
-                const double k = ws * inv;
-                sp[6] = k * (c0 * r0.x * r0.x + c1 * r1.x * r1.x + c2 * r2.x * r2.x - nh.x * nh.x);
-                sp[7] = k * (c0 * r0.x * r0.y + c1 * r1.x * r1.y + c2 * r2.x * r2.y - nh.x * nh.y);
-                sp[8] = k * (c0 * r0.x * r0.z + c1 * r1.x * r1.z + c2 * r2.x * r2.z - nh.x * nh.z);
-                sp[9] = k * (c0 * r0.y * r0.y + c1 * r1.y * r1.y + c2 * r2.y * r2.y - nh.y * nh.y);
-                sp[10] = k * (c0 * r0.y * r0.z + c1 * r1.y * r1.z + c2 * r2.y * r2.z - nh.y * nh.z);
-                sp[11] = k * (c0 * r0.z * r0.z + c1 * r1.z * r1.z + c2 * r2.z * r2.z - nh.z * nh.z);
-            } else {
-#pragma unroll
-                for (int k = 3; k < 12; k++) sp[k] = 0.0;
-            }
-            sp[12] = (double)jid;
-        }
-        wave_sync();
-        // ---- phase H: pair lane ----
-        if (pair) {
-            // torque rows: forward recursion on hyper-dual numbers, link-local frames
-            H3 va, vl, aa, al, wa, wl;
+
+        // ---- torque rows: this wavefront's seven pairs, lane = sample ----
+#pragma unroll 1
+        for (int it = 0; it < 7; it++) {
+            const int code = H_PAIR_OF[wave][it];
+            const int pa = code >> 3, pb = code & 7;
+            Kin<double> k0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                va.c[k] = hd(0.0); vl.c[k] = hd(0.0); aa.c[k] = hd(0.0); wa.c[k] = hd(0.0); wl.c[k] = hd(0.0);
-                al.c[k] = hd(M->neg_gravity[k]);  // base acceleration -a_grav (CustomizedInverseDynamics.cpp:212)
+                k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
+                k0.al.c[k] = M->neg_gravity[k];  // base acceleration -a_grav (CustomizedInverseDynamics.cpp:212)
             }
-            double phi_ab = 0.0;
+#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
+#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
+            int l = 0;
 #pragma unroll 1
-            for (int l = 0; l < NV; l++) {
-                const double* x = sl + HL_X + l * 5;
-                const double qa = (l == pa) ? 1.0 : 0.0, qb = (l == pb) ? 1.0 : 0.0;
-                const int jt = M->jtype[l];
-                const double sg = jt < 0 ? -1.0 : 1.0;
-                const double cq = x[2], sq = x[3];
-                const double da = qa * w0, db = qb * w0;
-                const HD C = HD{cq, -sq * da, -sq * db, -cq * da * db};
-                const HD Sn = sg * HD{sq, cq * da, cq * db, -sq * da * db};
-                const HD qd = HD{x[0], qa * w1, qb * w1, 0.0};
-                const HD qdd = HD{x[1], qa * w2, qb * w2, 0.0};
-                // Xtree = plux(R^T, p): [w; v] -> [R^T w; R^T (v + w x p)]   (CustomizedInverseDynamics.cpp:43-47, Utils.h:185-191)
-                const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
-                vl = mulT(M->plR[l], vl + cross(va, p));
-                va = mulT(M->plR[l], va);
-                al = mulT(M->plR[l], al + cross(aa, p));
-                aa = mulT(M->plR[l], aa);
-                wl = mulT(M->plR[l], wl + cross(wa, p));
-                wa = mulT(M->plR[l], wa);
-                const double mu = sl[HL_MU + l];
-                const int aj = jt < 0 ? -jt : jt;
-                if (aj == 3) hess_joint<2>(C, Sn, sg, qd, qdd, mu, va, vl, aa, al, wa, wl);
-                else if (aj == 2) hess_joint<1>(C, Sn, sg, qd, qdd, mu, va, vl, aa, al, wa, wl);
-                else hess_joint<0>(C, Sn, sg, qd, qdd, mu, va, vl, aa, al, wa, wl);
-                // f = I a + v x* (I v), I = (mass, lever, inertia about the COM) in the link frame (:244-246)
-                const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
-                const double mass = M->mass[l];
-                H3 hl = vl + cross(va, c);  // momentum: linear part / mass
-                H3 gl = al + cross(aa, c);
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    hl.c[k] = mass * hl.c[k];
-                    gl.c[k] = mass * gl.c[k];
+            for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
+            Kin<HD> kh;
+            if (pa < pb) {
+                Kin<D1> k1 = promote<D1>(k0);
+                {   // l == pa: seeded in z_a
+                    const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                    hess_link(M, l, D1{cq, -sq * w0}, sg * D1{sq, cq * w0}, D1{HX(l, 0), w1}, D1{HX(l, 1), w2},
+                              lds[HL_MU + l * H_CH + lane], k1);
+                    l++;
                 }
-                const H3 ha = symmul(M->Ic[l], va) + cross(c, hl);
-                const H3 ga = symmul(M->Ic[l], aa) + cross(c, gl);
-                const H3 fa = ga + cross(va, ha) + cross(vl, hl);
-                const H3 fl = gl + cross(va, hl);
-                phi_ab += dot_ab(wa, fa) + dot_ab(wl, fl);
-            }
-            acc += phi_ab;
-            // obstacle rows
-            if (O > 0) {
-                const double* wa_ = sl + HL_W + pa * 6;
-                const double* wb_ = sl + HL_W + pb * 6;
-                const V3 oma = v3(wa_[0], wa_[1], wa_[2]), oa = v3(wa_[3], wa_[4], wa_[5]);
-                const V3 omb = v3(wb_[0], wb_[1], wb_[2]), ob = v3(wb_[3], wb_[4], wb_[5]);
-                double so = 0.0;
 #pragma unroll 1
-                for (int s = 0; s < ns; s++) {
-                    const double* sp = sl + HL_SP + s * HL_SPW;
-                    if (pb < (int)sp[12]) {  // both joints move the sphere (columns c < joint id)
-                        const V3 pt = v3(sp[0], sp[1], sp[2]);
-                        const V3 Ja = cross(oma, pt - oa);
-                        const V3 Jb = cross(omb, pt - ob);
-                        const V3 Hab = cross(oma, Jb);
-                        const V3 KJb = symmul(sp[6], sp[7], sp[8], sp[9], sp[10], sp[11], Jb);
-                        so += dot(Ja, KJb) + dot(v3(sp[3], sp[4], sp[5]), Hab);
+                for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1);
+                kh = promote<HD>(k1);
+            } else {
+                kh = promote<HD>(k0);
+            }
+            double phi_ab;
+            {   // l == pb: seeded in z_b (and in z_a on the diagonal)
+                const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                const double da = (pa == pb) ? w0 : 0.0, ea = (pa == pb) ? w1 : 0.0, fa = (pa == pb) ? w2 : 0.0;
+                hess_link(M, l, HD{cq, -sq * da, -sq * w0, -cq * da * w0}, sg * HD{sq, cq * da, cq * w0, -sq * da * w0},
+                          HD{HX(l, 0), ea, w1, 0.0}, HD{HX(l, 1), fa, w2, 0.0}, lds[HL_MU + l * H_CH + lane], kh);
+                phi_ab = hess_power_ab(M, l, kh);
+                l++;
+            }
+#pragma unroll 1
+            for (; l < NV; l++) {
+                hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh);
+                phi_ab += hess_power_ab(M, l, kh);
+            }
+#undef HX
+#undef HSG
+            const double tot = wave_sum(live ? phi_ab : 0.0);
+            if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + H_PAIRS + pair_index(pa, pb)] += tot;
+        }
+        __syncthreads();  // world-frame tables complete
+
+        // ---- obstacle rows: a wavefront per sphere, lane = sample ----
+        if (O > 0) {
+            double acc[H_PAIRS];
+#pragma unroll
+            for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
+#pragma unroll 1
+            for (int sp = wave; sp < ns; sp += H_WAVES) {
+                const int jid = S->joint_id[sp];
+                const double* ro = lds + HL_RO + (S->ro_slot[jid - 1] * 12) * H_CH + lane;
+                M3 R;
+#pragma unroll
+                for (int k = 0; k < 9; k++) R.m[k] = ro[k * H_CH];
+                const V3 point = v3(ro[9 * H_CH], ro[10 * H_CH], ro[11 * H_CH]) +
+                                 mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+                BoxBest best;
+                best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
+                for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
+                const double wgt = live ? lam[L.off_obs + (i0 + lane) * ns + sp] * w0 * w0 : 0.0;
+                V3 ng = v3(0, 0, 0);
+                double K0 = 0, K1 = 0, K2 = 0, K3 = 0, K4 = 0, K5 = 0;
+                if (best.d2 > 1e-12) {  // SQUARE_ROOT_THRESHOLD, BoxCollisionAvoidance.cpp:458
+                    const DevBox* bx = boxes + best.idx;
+                    M3 Rb;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+                    const double inv = 1.0 / sqrt(best.d2);
+                    const V3 nh = mul(Rb, best.dl) * inv;  // diff / |diff| in the world frame
+                    const double ws = wgt * best.sign;
+                    ng = nh * ws;
+                    // P = sum over the clamped axes (dl != 0 exactly there: :233-250, :269-273) of r_k r_k^T
+                    const double c0 = (best.dl.x != 0.0) ? 1.0 : 0.0, c1 = (best.dl.y != 0.0) ? 1.0 : 0.0, c2 = (best.dl.z != 0.0) ? 1.0 : 0.0;
+                    const V3 r0 = col(Rb, 0), r1 = col(Rb, 1), r2 = col(Rb, 2);
+                    const double kk = ws * inv;
+                    K0 = kk * (c0 * r0.x * r0.x + c1 * r1.x * r1.x + c2 * r2.x * r2.x - nh.x * nh.x);
+                    K1 = kk * (c0 * r0.x * r0.y + c1 * r1.x * r1.y + c2 * r2.x * r2.y - nh.x * nh.y);
+                    K2 = kk * (c0 * r0.x * r0.z + c1 * r1.x * r1.z + c2 * r2.x * r2.z - nh.x * nh.z);
+                    K3 = kk * (c0 * r0.y * r0.y + c1 * r1.y * r1.y + c2 * r2.y * r2.y - nh.y * nh.y);
+                    K4 = kk * (c0 * r0.y * r0.z + c1 * r1.y * r1.z + c2 * r2.y * r2.z - nh.y * nh.z);
+                    K5 = kk * (c0 * r0.z * r0.z + c1 * r1.z * r1.z + c2 * r2.z * r2.z - nh.z * nh.z);
+                }
+                // columns c < joint id move the sphere (jid is wave-uniform: scalar branches)
+                V3 om[NV], Jc[NV];
+#pragma unroll
+                for (int c = 0; c < NV; c++) {
+                    if (c < jid) {
+                        const double* wv = lds + HL_W + (c * 6) * H_CH + lane;
+                        om[c] = v3(wv[0], wv[H_CH], wv[2 * H_CH]);
+                        Jc[c] = cross(om[c], point - v3(wv[3 * H_CH], wv[4 * H_CH], wv[5 * H_CH]));
                     }
                 }
-                acc += so;
+#pragma unroll
+                for (int cb = 0; cb < NV; cb++) {
+                    if (cb < jid) {
+                        const V3 KJ = symmul(K0, K1, K2, K3, K4, K5, Jc[cb]);
+                        const V3 nJ = cross(Jc[cb], ng);  // n . (w_a x J_b) = w_a . (J_b x n)
+#pragma unroll
+                        for (int ca = 0; ca <= cb; ca++) acc[ca * 7 - (ca * (ca - 1)) / 2 + (cb - ca)] += dot(Jc[ca], KJ) + dot(om[ca], nJ);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < H_PAIRS; k++) {
+                const double tot = wave_sum(acc[k]);
+                if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + k] += tot;
             }
         }
-        wave_sync();
+        __syncthreads();  // the sample tables are rewritten by the next pass
     }
 
-    // ---- the 8 partial sums, fixed order; hess_f = diag(pq_pz(tplan_n)^2) (KinovaOptimizer.cpp:243-247) ----
-    double* red = lds + H_GROUPS * HL_STRIDE;
-    red[grp * HG + t] = acc;
-    __syncthreads();
+    // ---- the partial sums in a fixed order; hess_f = diag(pq_pz(tplan_n)^2) (KinovaOptimizer.cpp:243-247) ----
     if (tid < H_PAIRS) {
         double s = 0.0;
 #pragma unroll
-        for (int g = 0; g < H_GROUPS; g++) s += red[g * HG + tid];
-        if (obj_factor != nullptr && pa == pb) {
+        for (int w = 0; w < H_WAVES; w++) s += lds[HL_ACC + w * 2 * H_PAIRS + tid] + lds[HL_ACC + w * 2 * H_PAIRS + H_PAIRS + tid];
+        int pa = 0, rem = tid;
+        while (rem >= NV - pa) {
+            rem -= NV - pa;
+            pa++;
+        }
+        if (obj_factor != nullptr && rem == 0) {
             const double w = wsum[tplan_n * 3];
             s += obj_factor[b] * (w * w);
         }
