@@ -148,10 +148,13 @@ RD void hess_link(const DevModel* __restrict__ M, int l, Tq C, Tq Sn, Tq qd, Tq 
     const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
     k.vl = mulT(M->plR[l], k.vl + cross(k.va, p));
     k.va = mulT(M->plR[l], k.va);
+
     k.al = mulT(M->plR[l], k.al + cross(k.aa, p));
     k.aa = mulT(M->plR[l], k.aa);
+
     k.wl = mulT(M->plR[l], k.wl + cross(k.wa, p));
     k.wa = mulT(M->plR[l], k.wa);
+
     const int jt = M->jtype[l];
     const double sg = jt < 0 ? -1.0 : 1.0;
     const int aj = jt < 0 ? -jt : jt;
@@ -170,9 +173,11 @@ RD double hess_power_ab(const DevModel* __restrict__ M, int l, const Kin<HD>& k)
         hl.c[i] = mass * hl.c[i];
         gl.c[i] = mass * gl.c[i];
     }
+
     const T3<HD> ha = symmul(M->Ic[l], k.va) + cross(c, hl);
     const T3<HD> fl = gl + cross(k.va, hl);
     double s = dot_ab(k.wl, fl);
+
     const T3<HD> fa = symmul(M->Ic[l], k.aa) + cross(c, gl) + cross(k.va, ha) + cross(k.vl, hl);
     return s + dot_ab(k.wa, fa);
 }

@@ -23,12 +23,30 @@ from test_oracle_pins import CAPSULE_KNOWN
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def kinova_hessian(oracle, kin, keep):
+    """KinovaOptimizer objective + Optimizer::eval_h at fixed (z, lambda, obj_factor): regression vectors of the oracle after
+    tests/test_oracle_hessian.py pinned it with the reference's finite-difference recipes."""
+    p = H.kinova_problem(oracle, kin, keep, N=4, boxes=H.reach_boxes(), gripper=True)
+    rng = np.random.default_rng(20250523 + 7)
+    q_des = rng.uniform(-3, 3, 7)
+    p.set_objective(q_des, 2)
+    Z = rng.uniform(-1, 1, (2, 7))
+    lam = rng.uniform(-1, 1, (2, p.m))
+    of = rng.uniform(0.5, 2.0, 2)
+    F, GR = p.objective_host(Z)
+    np.savez(os.path.join(OUT, "kinova_hessian_N4.npz"), Z=Z, lam=lam, obj_factor=of, q_des=q_des, tplan_n=np.array(2),
+             F=F, GRAD=GR, H=p.eval_h_host(Z, lam, of))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
     keep = []
     kin = raptor_amd.load_urdf(os.path.join(ROOT, "tests", "robots", "kinova.urdf"))
     kin.gravity = np.array([0.0, 0.0, -9.81])
+    kinova_hessian(oracle, kin, keep)
+    if "--hessian-only" in sys.argv:  # added after the other fixtures were committed: leaves them untouched
+        return
     p = H.kinova_problem(oracle, kin, keep, N=4, boxes=H.reach_boxes())
     Z = np.random.default_rng(20250523).uniform(-1, 1, (2, 7))
     G, J = p.eval_host(Z)

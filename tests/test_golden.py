@@ -61,3 +61,23 @@ def test_hip_matches_golden(hip, kinova, name):
         r = p.constrained_id_host(d["Z"], 2, nv, 12, derivatives=False)
         for key in ("q", "tau", "lam"):
             assert H.rel_err(r[key], d[key]) <= TOL
+
+
+def _hessian_case(api, kinova):
+    d = np.load(os.path.join(GOLD, "kinova_hessian_N4.npz"))
+    keep = []
+    p = H.kinova_problem(api, kinova, keep, N=4, boxes=H.reach_boxes(), gripper=True)
+    p.set_objective(d["q_des"], int(d["tplan_n"]))
+    F, GR = p.objective_host(d["Z"])
+    return d, F, GR, p.eval_h_host(d["Z"], d["lam"], d["obj_factor"])
+
+
+def test_oracle_reproduces_golden_hessian(oracle, kinova):
+    d, F, GR, Hh = _hessian_case(oracle, kinova)
+    assert H.rel_err(F, d["F"]) < 1e-12 and H.rel_err(GR, d["GRAD"]) < 1e-12 and H.rel_err(Hh, d["H"]) < 1e-11
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_hessian(hip, kinova):
+    d, F, GR, Hh = _hessian_case(hip, kinova)
+    assert H.rel_err(F, d["F"]) <= TOL and H.rel_err(GR, d["GRAD"]) <= TOL and H.rel_err(Hh, d["H"]) <= TOL
