@@ -284,6 +284,16 @@ def main() -> None:
             "sample_evals_per_s": B * W.samples / (ms * 1e-3),
             "batch": B, "samples": W.samples,
         }
+        if not args.no_latency:  # the Ipopt-driven use: one z per call, host-synchronised
+            reps = 100
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                prob.eval_h_device(Z.data_ptr(), 1, of.data_ptr(), lam.data_ptr(), Hh.data_ptr(), stream)
+                torch.cuda.synchronize()
+            rec["single_problem_eval_h_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
+            call()  # restore the batch results for the check below
+            torch.cuda.synchronize()
         if with_cpu:
             import helpers as H
 

@@ -2,7 +2,7 @@
 
 The compute lives in ``libraptor_hip.so`` (hand-written HIP, built in-tree from ``csrc/``) behind the
 C ABI of ``include/raptor_hip.h``.  This package is the thin host-side mirror of the reference's
-classes (``raptor_amd.host``) plus the URDF loader.  There is no CPU fallback: importing the API
+classes (``raptor_amd.optimizer``: the Optimizer / TNLP shell; ``raptor_amd._capi``: problem handles) plus the URDF loader.  There is no CPU fallback: importing the API
 without the built library raises.
 """
 from __future__ import annotations
