@@ -196,6 +196,11 @@ __device__ const unsigned char H_PAIR_OF[H_WAVES][7] = {
     {0 * 8 + 2, 1 * 8 + 2, 2 * 8 + 3, 4 * 8 + 4, 2 * 8 + 5, 1 * 8 + 6, 4 * 8 + 6}};
 RD int pair_index(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a); }  // upper triangle row by row (Optimizer.cpp:531-538)
 
+// SPLIT = false: one workgroup per decision vector (batches).  SPLIT = true: seven workgroups per decision vector
+// (blockIdx.y = slot): each wavefront takes ONE pair and every 28th sphere, the 28 partial sums go to `Hout` =
+// part[B][7][28] and kinova_hessian_reduce_kernel adds them in a fixed order -- the single-problem (Ipopt-driven) case,
+// where one workgroup per z would leave the chip idle.
+template <bool SPLIT>
 __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
 
         // ---- torque rows: this wavefront's seven pairs, lane = sample ----
 #pragma unroll 1
-        for (int it = 0; it < 7; it++) {
+        for (int it = SPLIT ? (int)blockIdx.y : 0; it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
             const int code = H_PAIR_OF[wave][it];
             const int pa = code >> 3, pb = code & 7;
             Kin<double> k0;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
 #pragma unroll
             for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
 #pragma unroll 1
-            for (int sp = wave; sp < ns; sp += H_WAVES) {
+            for (int sp = SPLIT ? wave + H_WAVES * (int)blockIdx.y : wave; sp < ns; sp += SPLIT ? 7 * H_WAVES : H_WAVES) {
                 const int jid = S->joint_id[sp];
                 const double* ro = lds + HL_RO + (S->ro_slot[jid - 1] * 12) * H_CH + lane;
                 M3 R;
@@ -395,12 +400,38 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
             rem -= NV - pa;
             pa++;
         }
-        if (obj_factor != nullptr && rem == 0) {
-            const double w = wsum[tplan_n * 3];
-            s += obj_factor[b] * (w * w);
+        if (SPLIT) {
+            Hout[(b * 7 + blockIdx.y) * H_PAIRS + tid] = s;
+        } else {
+            if (obj_factor != nullptr && rem == 0) {
+                const double w = wsum[tplan_n * 3];
+                s += obj_factor[b] * (w * w);
+            }
+            Hout[b * H_PAIRS + tid] = s;
         }
-        Hout[b * H_PAIRS + tid] = s;
     }
+}
+
+// second step of the split form: H[b][p] = sum over the seven slots (fixed order) + obj_factor * hess_f
+__global__ __launch_bounds__(64) void kinova_hessian_reduce_kernel(const double* __restrict__ part, const double* __restrict__ wsum,
+                                                                    const double* __restrict__ obj_factor, const int tplan_n,
+                                                                    const int B, double* __restrict__ Hout) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= B * H_PAIRS) return;
+    const int b = idx / H_PAIRS, p = idx - b * H_PAIRS;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s += part[((long long)b * 7 + k) * H_PAIRS + p];
+    int pa = 0, rem = p;
+    while (rem >= 7 - pa) {
+        rem -= 7 - pa;
+        pa++;
+    }
+    if (obj_factor != nullptr && rem == 0) {
+        const double w = wsum[tplan_n * 3];
+        s += obj_factor[b] * (w * w);
+    }
+    Hout[idx] = s;
 }
 
 // KinovaOptimizer::eval_f / eval_grad_f (KinovaOptimizer.cpp:152-218): one lane per decision vector.

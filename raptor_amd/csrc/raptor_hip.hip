@@ -125,6 +125,7 @@ struct raptor_problem {
     DevBuf<double> d_basis, d_wsum;
     DevBuf<DevSpheres> d_spheres;
     DevBuf<DevBox> d_boxes;
+    DevBuf<double> s_hpart; // eval_h, split form: partial Hessians [32][7][28]
     DevBuf<double> d_qdes;  // KinovaOptimizer::q_des, tplan_n (raptor_kinova_set_objective); tplan_n < 0: not set
     int tplan_n = -1;
     // staging for the *_host entry points (grown on demand, reused)
@@ -1445,9 +1446,21 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
     if (!p->hmodel.serial_chain) throw unsupported_error("eval_h kernel: serial-chain models only");
     for (int l = 0; l < p->hmodel.nv; l++)
         if (std::abs(p->hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
-    hipLaunchKernelGGL(kinova_hessian_kernel, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, p->d_model.p, p->d_traj.p,
-                       p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda,
-                       p->tplan_n < 0 ? 0 : p->tplan_n, d_H);
+    const int tplan = p->tplan_n < 0 ? 0 : p->tplan_n;
+    hipStream_t st = (hipStream_t)stream;
+    if (B <= 32) {  // few decision vectors (the Ipopt-driven case is B = 1): seven workgroups per z, then a fixed-order sum
+        p->s_hpart.ensure((size_t)32 * 7 * H_PAIRS);
+        hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
+                           p->s_hpart.p);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, p->s_hpart.p,
+                           p->d_wsum.p, d_obj_factor, tplan, B, d_H);
+    } else {
+        hipLaunchKernelGGL(kinova_hessian_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
+                           d_H);
+    }
     HIP_CHECK(hipGetLastError());
     API_CATCH
 }
