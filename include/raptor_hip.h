@@ -41,6 +41,7 @@ extern "C" {
 #define RAPTOR_TRAJ_ARMOUR_BEZIER 0 /* Trajectories/src/ArmourBezierCurves.cpp:44-163 */
 #define RAPTOR_TRAJ_BEZIER 1        /* Trajectories/src/BezierCurves.cpp:21-182      */
 #define RAPTOR_TRAJ_POLYNOMIAL 2    /* Trajectories/src/Polynomials.cpp:15-91 (used by the reference's ID tests) */
+#define RAPTOR_TRAJ_PIECEWISE_BEZIER 3 /* Trajectories/src/PiecewiseBezierCurves.cpp:5-255 (KinovaLongerHorizonOptimizer) */
 
 /* what raptor_eval_batch computes: G only == Constraints::compute(z,false) (eval_g),
  * JAC == Constraints::compute(z,true) (eval_jac_g).  */
@@ -79,12 +80,18 @@ typedef struct raptor_traj_desc {
     const double* q_d0;      /* [Nact] BEZIER: non-null (with q0) = constrainInitialVelocity(q_d0); each drops Nact variables
                                 (BezierCurves.cpp:39-69, second coefficient row q0 + q_d0 T / 5.0 as written at :86)         */
     const double* q_dd0;     /* [Nact]                                                          */
+    const double* qT;        /* [Nact] PIECEWISE_BEZIER only: end position; NULL = optimised, stored at the end of z.  There q0 is
+                                the begin position (NULL = optimised too), `degree` the number of interior control points
+                                (degree + 1 quintic pieces, N a multiple of degree + 1), time_discretization is ignored
+                                (always LinSpaced, PiecewiseBezierCurves.cpp:22)                                             */
 } raptor_traj_desc;
 
 /* Arguments of KinovaOptimizer::set_parameters
  * (Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaOptimizer.cpp:18-116). */
 typedef struct raptor_kinova_desc {
-    raptor_traj_desc traj;               /* must be ARMOUR_BEZIER with Nact == model nv == 7    */
+    raptor_traj_desc traj;               /* ARMOUR_BEZIER (KinovaOptimizer) or PIECEWISE_BEZIER (KinovaLongerHorizonOptimizer:
+                                            Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaLongerHorizonOptimizer.cpp:18-122,
+                                            same four blocks), Nact == model nv == 7 */
     int num_obstacles;
     const double* box_center;            /* [O*3] boxCenters                                    */
     const double* box_rpy;               /* [O*3] boxOrientation (roll,pitch,yaw)               */

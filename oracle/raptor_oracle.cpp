@@ -360,7 +360,10 @@ struct Trajectory {
     int type = 0, degree = 0, N = 0, Nact = 0, varLength = 0;
     double T = 0;
     std::vector<double> tspan;
-    VecX q0, q_d0, q_dd0;
+    VecX q0, q_d0, q_dd0, qT;
+    // PiecewiseBezierCurves.h:36-54
+    bool optimize_begin_position = false, optimize_end_position = false;
+    int begin_position_offset = 0, end_position_offset = 0;
     int fixed_rows = 0;  // BezierCurves: 1 after constrainInitialPosition, 2 after constrainInitialVelocity
     MatX coefficients;  // (degree+1) x Nact
     VecX Bionomials;
@@ -379,7 +382,11 @@ struct Trajectory {
         if (degree < 1) throw std::invalid_argument("traj: degree must be positive");
         // Trajectories.cpp:54-64
         tspan.assign(N, 0.0);
-        if (d->time_discretization == RAPTOR_TIME_UNIFORM) {
+        if (type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {  // PiecewiseBezierCurves.cpp:18-22: always LinSpaced(N, 0, T)
+            if (N % (degree + 1) != 0) throw std::invalid_argument("PiecewiseBezierCurves: N must be a multiple of (degree + 1)");
+            for (int i = 0; i < N; i++) tspan[i] = (N == 1) ? T : (0.0 + i * ((T - 0.0) / (N - 1)));
+            if (N > 1) tspan[N - 1] = T;
+        } else if (d->time_discretization == RAPTOR_TIME_UNIFORM) {
             // Eigen LinSpaced(N, 0, T): low + i*step, last element forced to high
             for (int i = 0; i < N; i++) tspan[i] = (N == 1) ? T : (0.0 + i * ((T - 0.0) / (N - 1)));
             if (N > 1) tspan[N - 1] = T;
@@ -402,6 +409,21 @@ struct Trajectory {
                 coefficients(1, j) = q0[j] + (T * q_d0[j]) / 5.0;
                 coefficients(2, j) = q0[j] + (2.0 * T * q_d0[j]) / 5.0 + (T * T * q_dd0[j]) / 20.0;
             }
+        } else if (type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {  // PiecewiseBezierCurves.cpp:34-47
+            varLength = Nact * degree * 3;
+            if (d->q0) q0.assign(d->q0, d->q0 + Nact);
+            if (d->qT) qT.assign(d->qT, d->qT + Nact);
+            if ((int)q0.size() != Nact) {
+                optimize_begin_position = true;
+                begin_position_offset = varLength;
+                varLength += Nact;
+            }
+            if ((int)qT.size() != Nact) {
+                optimize_end_position = true;
+                end_position_offset = varLength;
+                varLength += Nact;
+            }
+            coefficients = MatX(6, Nact);
         } else if (type == RAPTOR_TRAJ_BEZIER || type == RAPTOR_TRAJ_POLYNOMIAL) {
             varLength = (degree + 1) * Nact;
             coefficients = MatX(degree + 1, Nact);
@@ -424,7 +446,13 @@ struct Trajectory {
         } else {
             throw std::invalid_argument("traj: unknown trajectory type");
         }
-        if (type != RAPTOR_TRAJ_POLYNOMIAL) {
+        if (type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {  // PiecewiseBezierCurves.cpp:28-32: quintic pieces
+            Bionomials.assign(6, 1.0);
+            for (int j = 1; j <= 2; j++) {
+                Bionomials[j] = Bionomials[j - 1] * (6 - j) / j;
+                Bionomials[5 - j] = Bionomials[j];
+            }
+        } else if (type != RAPTOR_TRAJ_POLYNOMIAL) {
             // BezierCurves.cpp:32-36
             Bionomials.assign(degree + 1, 1.0);
             for (int j = 1; j <= degree / 2; j++) {
@@ -478,7 +506,94 @@ struct Trajectory {
         }
     }
 
+    // PiecewiseBezierCurves::compute (PiecewiseBezierCurves.cpp:52-255)
+    void compute_piecewise(const double* z, bool compute_derivatives) {
+        const int seg_size = N / (degree + 1);
+        const double localT = T / (degree + 1);
+        for (int x = 0; x < N; x++) {
+            const int id = x / seg_size;                              // :68
+            const double t = (tspan[x] - id * localT) / localT;       // :71
+            const double velocity_factor = localT / 5.0;              // :74-75
+            const double acceleration_factor = localT * localT / 20.0;
+            VecX begin_q(Nact, 0.0), begin_q_d(Nact, 0.0), begin_q_dd(Nact, 0.0), end_q(Nact, 0.0), end_q_d(Nact, 0.0), end_q_dd(Nact, 0.0);
+            for (int j = 0; j < Nact; j++) {                          // :81-123
+                if (id == 0) {
+                    begin_q[j] = optimize_begin_position ? z[begin_position_offset + j] : q0[j];
+                } else {
+                    const double* cp = z + (id - 1) * 3 * Nact;
+                    begin_q[j] = cp[j]; begin_q_d[j] = cp[Nact + j]; begin_q_dd[j] = cp[2 * Nact + j];
+                }
+                if (id == degree) {
+                    end_q[j] = optimize_end_position ? z[end_position_offset + j] : qT[j];
+                } else {
+                    const double* cp = z + id * 3 * Nact;
+                    end_q[j] = cp[j]; end_q_d[j] = cp[Nact + j]; end_q_dd[j] = cp[2 * Nact + j];
+                }
+                coefficients(0, j) = begin_q[j];                       // :127-138
+                coefficients(1, j) = begin_q[j] + begin_q_d[j] * velocity_factor;
+                coefficients(2, j) = begin_q[j] + begin_q_d[j] * 2.0 * velocity_factor + begin_q_dd[j] * acceleration_factor;
+                coefficients(3, j) = end_q[j] - end_q_d[j] * 2.0 * velocity_factor + end_q_dd[j] * acceleration_factor;
+                coefficients(4, j) = end_q[j] - end_q_d[j] * velocity_factor;
+                coefficients(5, j) = end_q[j];
+            }
+            double tA[6], tB[6], dtA[6], dtB[6], ddtA[6], ddtB[6], B[6], dB[6], ddB[6];  // :143-167
+            for (int k = 0; k < 6; k++) { tA[k] = 1; tB[k] = 1; dtA[k] = 0; dtB[k] = 0; ddtA[k] = 0; ddtB[k] = 0; }
+            for (int j = 1; j <= 5; j++) {
+                tA[j] = t * tA[j - 1];
+                tB[5 - j] = (1 - t) * tB[5 - j + 1];
+                dtA[j] = j * tA[j - 1];
+                dtB[5 - j] = -j * tB[5 - j + 1];
+                ddtA[j] = j * dtA[j - 1];
+                ddtB[5 - j] = -j * dtB[5 - j + 1];
+            }
+            for (int k = 0; k < 6; k++) {
+                B[k] = Bionomials[k] * tA[k] * tB[k];
+                dB[k] = Bionomials[k] * (dtA[k] * tB[k] + tA[k] * dtB[k]) / localT;
+                ddB[k] = Bionomials[k] * (ddtA[k] * tB[k] + 2 * dtA[k] * dtB[k] + tA[k] * ddtB[k]) / (localT * localT);
+            }
+            for (int j = 0; j < Nact; j++) {  // :175-177
+                double s0 = 0, s1 = 0, s2 = 0;
+                for (int k = 0; k < 6; k++) {
+                    s0 += coefficients(k, j) * B[k];
+                    s1 += coefficients(k, j) * dB[k];
+                    s2 += coefficients(k, j) * ddB[k];
+                }
+                q[x][j] = s0; q_d[x][j] = s1; q_dd[x][j] = s2;
+            }
+            if (!compute_derivatives) continue;
+            pq_pz[x].setZero(); pq_d_pz[x].setZero(); pq_dd_pz[x].setZero();
+            MatX* P[3] = {&pq_pz[x], &pq_d_pz[x], &pq_dd_pz[x]};
+            const double* Bs[3] = {B, dB, ddB};
+            for (int o = 0; o < 3; o++) {
+                const double* b = Bs[o];
+                MatX& M = *P[o];
+                for (int i = 0; i < Nact; i++) {
+                    if (id < degree) {  // columns of the control point that ends this piece (:186-194, :234-242)
+                        const int c0 = id * 3 * Nact + i;
+                        M(i, c0) = b[3] + b[4] + b[5];
+                        M(i, c0 + Nact) = -b[3] * 2.0 * velocity_factor - b[4] * velocity_factor;
+                        M(i, c0 + 2 * Nact) = b[3] * acceleration_factor;
+                    } else if (optimize_end_position) {  // :215-219
+                        M(i, end_position_offset + i) = b[3] + b[4] + b[5];
+                    }
+                    if (id > 0) {  // columns of the control point that begins this piece (:205-213, :224-232)
+                        const int c0 = (id - 1) * 3 * Nact + i;
+                        M(i, c0) = b[0] + b[1] + b[2];
+                        M(i, c0 + Nact) = b[1] * velocity_factor + b[2] * 2.0 * velocity_factor;
+                        M(i, c0 + 2 * Nact) = b[2] * acceleration_factor;
+                    } else if (optimize_begin_position) {  // :196-200
+                        M(i, begin_position_offset + i) = b[0] + b[1] + b[2];
+                    }
+                }
+            }
+        }
+    }
+
     void compute(const double* z, bool compute_derivatives) {
+        if (type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {
+            compute_piecewise(z, compute_derivatives);
+            return;
+        }
         if (type == RAPTOR_TRAJ_ARMOUR_BEZIER) {
             for (int j = 0; j < Nact; j++) {  // ArmourBezierCurves.cpp:96-99
                 const double qfinal = q0[j] + z[j];
@@ -1286,7 +1401,8 @@ int oracle_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     std::unique_ptr<raptor_problem> pr(new raptor_problem());
     Problem& p = pr->p;
     p.model = model->m;
-    if (d->traj.type != RAPTOR_TRAJ_ARMOUR_BEZIER) throw std::invalid_argument("KinovaOptimizer uses ArmourBezierCurves");
+    if (d->traj.type != RAPTOR_TRAJ_ARMOUR_BEZIER && d->traj.type != RAPTOR_TRAJ_PIECEWISE_BEZIER)
+        throw std::invalid_argument("KinovaOptimizer uses ArmourBezierCurves, KinovaLongerHorizonOptimizer PiecewiseBezierCurves");
     p.traj.init(&d->traj);
     if (p.model.nv != 7 || p.traj.Nact != 7) throw std::invalid_argument("KinovaOptimizer: NUM_JOINTS is 7");
     if (d->num_obstacles < 0) throw std::invalid_argument("num_obstacles < 0");

@@ -23,6 +23,7 @@ TIME_CHEBYSHEV = 1
 TRAJ_ARMOUR_BEZIER = 0
 TRAJ_BEZIER = 1
 TRAJ_POLYNOMIAL = 2
+TRAJ_PIECEWISE_BEZIER = 3
 EVAL_G = 1
 EVAL_JAC = 2
 COST_MINIMIZE_POWER = 0
@@ -62,6 +63,7 @@ class TrajDesc(C.Structure):
         ("q0", _dp),
         ("q_d0", _dp),
         ("q_dd0", _dp),
+        ("qT", _dp),
     ]
 
 
@@ -375,10 +377,10 @@ class ModelHandle:
 
 
 def make_traj_desc(keep: list, type: int, T: float, N: int, Nact: int, degree: int = 5,
-                   time_discretization: int = TIME_CHEBYSHEV, q0=None, q_d0=None, q_dd0=None) -> TrajDesc:
+                   time_discretization: int = TIME_CHEBYSHEV, q0=None, q_d0=None, q_dd0=None, qT=None) -> TrajDesc:
     t = TrajDesc()
     t.type, t.degree, t.T, t.N, t.time_discretization, t.Nact = type, degree, T, N, time_discretization, Nact
-    for name, val in (("q0", q0), ("q_d0", q_d0), ("q_dd0", q_dd0)):
+    for name, val in (("q0", q0), ("q_d0", q_d0), ("q_dd0", q_dd0), ("qT", qT)):
         if val is not None:
             arr = _f64(val)
             keep.append(arr)

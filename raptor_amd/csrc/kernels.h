@@ -44,6 +44,23 @@ RD void traj_joint(const DevTraj* __restrict__ T, const double* __restrict__ bas
             s1 += ck * B1[k];
             s2 += ck * B2[k];
         }
+    } else if (T->type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {
+        // PiecewiseBezierCurves is linear in z and column c moves joint c % Nact only: dense per-sample column weights
+        // W[i][order][c] (pq_pz / pq_d_pz / pq_dd_pz entries, PiecewiseBezierCurves.cpp:184-243) + the q0 / qT contribution
+        const int V = T->varLength, Nact = T->Nact;
+        const double* W0 = basis + (size_t)(i * 3) * V;
+        const double* W1 = W0 + V;
+        const double* W2 = W1 + V;
+        for (int c = j; c < V; c += Nact) {
+            const double zc = z[c];
+            s0 += W0[c] * zc;
+            s1 += W1[c] * zc;
+            s2 += W2[c] * zc;
+        }
+        const double* fx = basis + (size_t)T->N * 3 * V + (size_t)(i * 3) * Nact + j;
+        s0 += fx[0];
+        s1 += fx[Nact];
+        s2 += fx[2 * Nact];
     } else {
         const double* zj = z + j * K;  // column-major reshape (Utils.h:142-146)
         for (int k = 0; k < K; k++) {
@@ -72,6 +89,13 @@ RD void column_direction(const DevTraj* __restrict__ T, const double* __restrict
         w0 = wsum[i * 3];
         w1 = wsum[i * 3 + 1];
         w2 = wsum[i * 3 + 2];
+    } else if (T->type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {
+        const int V = T->varLength;
+        jd = c % T->Nact;
+        const double* W0 = basis + (size_t)(i * 3) * V;
+        w0 = W0[c];
+        w1 = W0[V + c];
+        w2 = W0[2 * V + c];
     } else {
         const int K = T->K;
         jd = c / K;

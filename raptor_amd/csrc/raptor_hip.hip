@@ -21,6 +21,7 @@
 #include "digit_kernel.h"
 #include "period_kernel.h"
 #include "kinova_hess_kernel.h"
+#include "sphere_rows_kernel.h"
 #include "digit_constants.h"
 #include "digit_tables.h"
 
@@ -173,6 +174,80 @@ void fill_model(const raptor_model_desc* d, DevModel& m) {
     for (int k = 0; k < 3; k++) m.neg_gravity[k] = -d->gravity[k];  // CustomizedInverseDynamics.cpp:212
 }
 
+// PiecewiseBezierCurves (Trajectories/src/PiecewiseBezierCurves.cpp:5-255): degree + 1 quintic pieces through `degree` interior
+// control points (q, q_d, q_dd each), zero velocity / acceleration at both ends.  The trajectory is linear in z and column c
+// moves joint c % Nact only, so the kernels get dense per-sample column weights W[i][order][c] (the entries of pq_pz, pq_d_pz,
+// pq_dd_pz, :184-243) followed by the constant part fx[i][order][j] (q0 / qT when they are not optimised).
+void fill_traj_piecewise(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan, std::vector<double>& basis,
+                         std::vector<double>& wsum) {
+    const int N = d->N, Nact = d->Nact, degree = d->degree;
+    const double T = d->T;
+    if (degree < 1) throw std::invalid_argument("traj: degree out of range");
+    if (N % (degree + 1) != 0) throw std::invalid_argument("PiecewiseBezierCurves: N must be a multiple of (degree + 1)");  // :18-20
+    t.degree = degree;
+    int V = Nact * degree * 3;  // :34-45
+    int begin_off = -1, end_off = -1;
+    if (!d->q0) { begin_off = V; V += Nact; }
+    if (!d->qT) { end_off = V; V += Nact; }
+    t.varLength = V;
+    t.K = V / Nact;
+    tspan.assign(N, 0.0);
+    for (int i = 0; i < N; i++) tspan[i] = (N == 1) ? T : (0.0 + i * ((T - 0.0) / (N - 1)));  // LinSpaced(N, 0, T), :22
+    if (N > 1) tspan[N - 1] = T;
+    wsum.assign((size_t)N * 3, 0.0);
+    basis.assign((size_t)N * 3 * V + (size_t)N * 3 * Nact, 0.0);
+    const int seg_size = N / (degree + 1);
+    const double localT = T / (degree + 1);
+    const double vf = localT / 5.0, af = localT * localT / 20.0;  // :74-75
+    const double binom[6] = {1, 5, 10, 10, 5, 1};
+    for (int x = 0; x < N; x++) {
+        const int id = x / seg_size;
+        const double tt = (tspan[x] - id * localT) / localT;
+        double tA[6], tB[6], dtA[6], dtB[6], ddtA[6], ddtB[6], Bs[3][6];
+        for (int k = 0; k < 6; k++) { tA[k] = 1; tB[k] = 1; dtA[k] = 0; dtB[k] = 0; ddtA[k] = 0; ddtB[k] = 0; }
+        for (int j = 1; j <= 5; j++) {  // :151-160
+            tA[j] = tt * tA[j - 1];
+            tB[5 - j] = (1 - tt) * tB[5 - j + 1];
+            dtA[j] = j * tA[j - 1];
+            dtB[5 - j] = -j * tB[5 - j + 1];
+            ddtA[j] = j * dtA[j - 1];
+            ddtB[5 - j] = -j * dtB[5 - j + 1];
+        }
+        for (int k = 0; k < 6; k++) {  // :162-167
+            Bs[0][k] = binom[k] * tA[k] * tB[k];
+            Bs[1][k] = binom[k] * (dtA[k] * tB[k] + tA[k] * dtB[k]) / localT;
+            Bs[2][k] = binom[k] * (ddtA[k] * tB[k] + 2 * dtA[k] * dtB[k] + tA[k] * ddtB[k]) / (localT * localT);
+        }
+        for (int o = 0; o < 3; o++) {
+            const double* b = Bs[o];
+            double* W = &basis[(size_t)(x * 3 + o) * V];
+            double* fx = &basis[(size_t)N * 3 * V + (size_t)(x * 3 + o) * Nact];
+            for (int i = 0; i < Nact; i++) {
+                if (id < degree) {  // the control point that ends this piece
+                    const int c0 = id * 3 * Nact + i;
+                    W[c0] = b[3] + b[4] + b[5];
+                    W[c0 + Nact] = -b[3] * 2.0 * vf - b[4] * vf;
+                    W[c0 + 2 * Nact] = b[3] * af;
+                } else if (end_off >= 0) {
+                    W[end_off + i] = b[3] + b[4] + b[5];
+                } else {
+                    fx[i] += d->qT[i] * (b[3] + b[4] + b[5]);
+                }
+                if (id > 0) {  // the control point that begins this piece
+                    const int c0 = (id - 1) * 3 * Nact + i;
+                    W[c0] = b[0] + b[1] + b[2];
+                    W[c0 + Nact] = b[1] * vf + b[2] * 2.0 * vf;
+                    W[c0 + 2 * Nact] = b[2] * af;
+                } else if (begin_off >= 0) {
+                    W[begin_off + i] = b[0] + b[1] + b[2];
+                } else {
+                    fx[i] += d->q0[i] * (b[0] + b[1] + b[2]);
+                }
+            }
+        }
+    }
+}
+
 // Trajectory constructor + per-sample basis tables (Trajectories.cpp:45-69, BezierCurves.cpp:21-37,117-141,
 // Polynomials.cpp:54-68, ArmourBezierCurves.cpp:63-69).  Pure set-up: runs once per problem.
 void fill_traj(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan, std::vector<double>& basis,
@@ -208,6 +283,9 @@ void fill_traj(const raptor_traj_desc* d, DevTraj& t, std::vector<double>& tspan
             t.varLength -= t.nfixed * d->Nact;
             if (d->degree + 1 - t.nfixed < 1) throw std::invalid_argument("traj: degree too low for the constrained initial state");
         }
+    } else if (d->type == RAPTOR_TRAJ_PIECEWISE_BEZIER) {
+        fill_traj_piecewise(d, t, tspan, basis, wsum);
+        return;
     } else {
         throw std::invalid_argument("traj: unknown trajectory type");
     }
@@ -345,6 +423,19 @@ void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     HIP_CHECK(hipGetLastError());
 }
 
+// KinovaCustomizedConstraints rows for any trajectory whose columns move one joint each (sphere_rows_kernel.h)
+void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
+    const int ns = p.hspheres.num_spheres;
+    const long long E = (long long)B * p.htraj.N;
+    if (E == 0 || ns == 0) return;
+    const unsigned grid = (unsigned)((E + SR_EPB - 1) / SR_EPB);
+    if (dJ) hipLaunchKernelGGL((sphere_rows_kernel<true>), dim3(grid), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
+                               p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
+    else hipLaunchKernelGGL((sphere_rows_kernel<false>), dim3(grid), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
+                            p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
+    HIP_CHECK(hipGetLastError());
+}
+
 // core kernel (values + compact derivative records), then the streaming expansion into pg_pz
 void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st) {
     const long long E = (long long)B * p.htraj.N;
@@ -449,6 +540,11 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     if (p.kind == 1) {  // Kinova: one fused kernel
         if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
         else launch_kinova<false>(p, dZ, B, dG, nullptr, st);
+    } else if (p.kind == 3) {  // Kinova, longer horizon: limit rows per column, then the sphere rows
+        if (!p.hmodel.serial_chain) throw unsupported_error("inverse dynamics kernel: only serial-chain models are built so far");
+        if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
+        else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
+        launch_sphere_rows(p, dZ, B, dG, jac ? dJ : nullptr, st);
     } else if (p.kind == 2) {  // legged: core kernel, then the streaming expansion (timed separately)
         launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st, prof ? p.ev[p.ev_used + 1] : nullptr);
     } else {
@@ -524,9 +620,11 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     API_TRY
     if (!model || !d || !out) throw std::invalid_argument("null argument");
     std::unique_ptr<raptor_problem> p(new raptor_problem());
-    p->kind = 1;
     p->hmodel = model->h;
-    if (d->traj.type != RAPTOR_TRAJ_ARMOUR_BEZIER) throw std::invalid_argument("KinovaOptimizer uses ArmourBezierCurves");
+    if (d->traj.type != RAPTOR_TRAJ_ARMOUR_BEZIER && d->traj.type != RAPTOR_TRAJ_PIECEWISE_BEZIER)
+        throw std::invalid_argument("KinovaOptimizer uses ArmourBezierCurves, KinovaLongerHorizonOptimizer PiecewiseBezierCurves");
+    // 1: KinovaOptimizer (fused kernels, diagonal pq_pz); 3: KinovaLongerHorizonOptimizer (per-column kernels)
+    p->kind = (d->traj.type == RAPTOR_TRAJ_ARMOUR_BEZIER) ? 1 : 3;
     std::vector<double> basis, wsum;
     fill_traj(&d->traj, p->htraj, p->tspan, basis, wsum);
     if (p->hmodel.nv != 7 || p->htraj.Nact != 7) throw std::invalid_argument("KinovaOptimizer: NUM_JOINTS is 7");
@@ -604,7 +702,7 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
 
     // layout, KinovaOptimizer.cpp:82-109
     const int r7 = N * 7, rs = N * S.num_spheres;
-    p->layout = DevLayout{3 * r7 + rs, 7, 0, r7, 2 * r7, 3 * r7};
+    p->layout = DevLayout{3 * r7 + rs, p->htraj.varLength, 0, r7, 2 * r7, 3 * r7};
     p->num_blocks = 4;
     p->block_offsets[0] = 0;
     p->block_offsets[1] = r7;
@@ -1440,6 +1538,7 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
     API_TRY
     if (!p || (B > 0 && (!d_Z || !d_lambda || !d_H))) throw std::invalid_argument("null argument");
     if (B < 0) throw std::invalid_argument("B < 0");
+    if (p->kind == 3) throw unsupported_error("eval_h: not built for PiecewiseBezierCurves (run Ipopt with hessian_approximation limited-memory)");
     if (p->kind != 1) throw std::runtime_error("eval_h: enable_hessian is false for this optimizer");  // Optimizer.cpp:513-515
     if (d_obj_factor && p->tplan_n < 0) throw std::invalid_argument("eval_h: raptor_kinova_set_objective has not been called");
     if (B == 0) return RAPTOR_OK;

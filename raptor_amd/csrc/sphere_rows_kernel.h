@@ -1,0 +1,108 @@
+// K_sphere_rows : KinovaCustomizedConstraints rows (sphere vs oriented boxes) for ANY trajectory whose columns move one joint
+// each -- used by the KinovaLongerHorizonOptimizer path (PiecewiseBezierCurves: 21 * degree (+14) columns), where the fused
+// Kinova kernel's "column = joint" layout does not apply.
+//   KinovaCustomizedConstraints::compute   Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaCustomizedConstraints.cpp:73-158
+//   BoxCollisionAvoidance::computeDistance Constraints/src/BoxCollisionAvoidance.cpp:92-204, 312-373
+//
+// 32 lanes per sample-eval, 8 sample-evals per workgroup.  Lanes 0..6 of a group evaluate the trajectory and sincos of their
+// joint (LDS exchange inside the half-wave); lane sp < ns walks the chain to its sphere's joint, finds the arg-min box (the
+// Jacobian kernel's code and tie rules) and leaves the distance's gradient per JOINT, d dist / d q_c = s_c . [p x n ; n], in
+// LDS.  The reference's 3 x nv translation Jacobian times pq_pz (:112) is then one multiply per output entry,
+//     pg_pz(row, c) = (d dist / d q_{joint(c)}) * pq_pz(joint(c), c),
+// written by the whole workgroup as one flat, contiguous stream (the obstacle rows of consecutive samples are adjacent).
+#ifndef RAPTOR_SPHERE_ROWS_KERNEL_H
+#define RAPTOR_SPHERE_ROWS_KERNEL_H
+
+#include "kinova_kernel.h"
+
+#define SR_LPE 32   // lanes per sample-eval (>= RAPTOR_MAX_SPHERES)
+#define SR_EPB 8    // sample-evals per workgroup
+#define SR_NV 7
+
+template <bool DERIV>
+__global__ __launch_bounds__(RAPTOR_BLOCK) void sphere_rows_kernel(
+    const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
+    const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
+    const double* __restrict__ Z, const long long E, double* __restrict__ G, double* __restrict__ JAC) {
+    __shared__ double lx[SR_EPB][SR_NV][3];                       // cos q, sin q, q
+    __shared__ double lg[SR_EPB][RAPTOR_MAX_SPHERES][SR_NV];      // d dist / d q_c per sphere
+    const int tid = threadIdx.x;
+    const int sp = tid & (SR_LPE - 1);
+    const int el = tid >> 5;
+    const long long e0 = (long long)blockIdx.x * SR_EPB;
+    const long long e = e0 + el;
+    const int N = T->N, V = L.n;
+    const int ns = S->num_spheres, O = S->num_obstacles;
+    const bool valid = e < E;
+    const int i = valid ? (int)(e % N) : 0;
+    const long long b = valid ? e / N : 0;
+    const double* z = Z + b * V;
+
+    if (valid && sp < SR_NV) {
+        double q, qd, qdd, sq, cq;
+        traj_joint(T, basis, z, i, sp, q, qd, qdd);
+        sincos(q, &sq, &cq);
+        lx[el][sp][0] = cq; lx[el][sp][1] = sq; lx[el][sp][2] = q;
+    }
+    wave_sync();
+
+    if (valid && sp < ns) {
+        const size_t row = (size_t)b * L.m + L.off_obs + (size_t)i * ns + sp;
+        if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
+            if (G != nullptr) G[row] = 0.0;
+#pragma unroll
+            for (int c = 0; c < SR_NV; c++) lg[el][sp][c] = 0.0;
+        } else {
+            const int jid = S->joint_id[sp];
+            M3 Rw;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            V3 ow = v3(0, 0, 0);
+            SV sv[SR_NV];
+#pragma unroll
+            for (int l = 0; l < SR_NV; l++) {
+                sv[l] = sv_zero();
+                if (l < jid) {
+                    const M3 A = mul(Rw, M->plR[l]);
+                    V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+                    M3 R;
+                    joint_world(M->jtype[l], lx[el][l][2], lx[el][l][0], lx[el][l][1], A, R, o, sv[l]);
+                    Rw = R;
+                    ow = o;
+                }
+            }
+            const V3 point = ow + mul(Rw, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+            BoxBest best;
+            best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
+            for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
+            if (G != nullptr) G[row] = box_best_distance(best) - S->radius[sp];  // :145
+            if (DERIV) {
+                const SV Wr = box_gradient_wrench(boxes + best.idx, best, point, 1.0);
+#pragma unroll
+                for (int c = 0; c < SR_NV; c++) lg[el][sp][c] = (c < jid) ? dot(sv[c], Wr) : 0.0;
+            }
+        }
+    }
+    if (!DERIV) return;
+    __syncthreads();
+
+    // ---- flat copy-out: rows (el, sp) x V columns; consecutive (el, sp) are consecutive rows unless b changes ----
+    const long long eend = (e0 + SR_EPB < E) ? e0 + SR_EPB : E;
+    const int nrows = (int)(eend - e0) * ns;
+    const long long total = (long long)nrows * V;
+    for (long long idx = tid; idx < total; idx += RAPTOR_BLOCK) {
+        const int r = (int)(idx / V);
+        const int c = (int)(idx - (long long)r * V);
+        const int rel = r / ns;
+        const int rsp = r - rel * ns;
+        const long long re = e0 + rel;
+        const int ri = (int)(re % N);
+        const long long rb = re / N;
+        int jd;
+        double w0, w1, w2;
+        column_direction(T, basis, wsum, ri, c, jd, w0, w1, w2);
+        JAC[((size_t)rb * L.m + L.off_obs + (size_t)ri * ns + rsp) * V + c] = lg[rel][rsp][jd] * w0;
+    }
+}
+
+#endif

@@ -664,3 +664,60 @@ def test_legged_ragged_and_degenerate_sizes(oracle, hip):
             A.ProblemHandle.legged(api, mm, A.make_traj_desc(keep, A.TRAJ_BEZIER, ct.T, 4, 12, ct.degree, A.TIME_CHEBYSHEV), bad)
         with pytest.raises(A.RaptorInvalidArgument):  # single-step optimizers use BezierCurves
             A.ProblemHandle.legged(api, mm, A.make_traj_desc(keep, A.TRAJ_POLYNOMIAL, ct.T, 4, 12, 3, A.TIME_CHEBYSHEV), ct)
+
+
+# ---------------------------------------------------------------- PiecewiseBezierCurves / KinovaLongerHorizonOptimizer
+def longer_horizon_problem(api, model, keep, degree=3, N=24, T=3.0, q0=None, qT=None, boxes=None, gripper=False):
+    """KinovaLongerHorizonOptimizer::set_parameters (KinovaLongerHorizonOptimizer.cpp:18-122): the four Kinova blocks over
+    PiecewiseBezierCurves(T, N, nq, degree, q0, qT)."""
+    mh = api.model_create(model)
+    keep.append(mh)
+    t = A.make_traj_desc(keep, A.TRAJ_PIECEWISE_BEZIER, T, N, 7, degree, A.TIME_UNIFORM, q0=q0, qT=qT)
+    c, rpy, size = boxes if boxes is not None else H.reach_boxes()
+    return A.ProblemHandle.kinova(api, mh, t, c, rpy, size, include_gripper=gripper)
+
+
+@pytest.mark.parametrize("fixed_ends", [True, False])
+def test_piecewise_inverse_dynamics(oracle, hip, kinova_friction, fixed_ends):
+    from test_oracle_pins import piecewise_problem
+
+    rng = np.random.default_rng(17)
+    q0, qT = (rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)) if fixed_ends else (None, None)
+    po, ph, keep = both(oracle, hip, lambda api, k: piecewise_problem(api, kinova_friction, k, 3, 24, 2.0, q0, qT))
+    assert po.n == ph.n == 63 + (0 if fixed_ends else 14)
+    Z = rng.uniform(-1, 1, (3, po.n))
+    for a, b in zip(ph.trajectory_host(Z, 24, 7), po.trajectory_host(Z, 24, 7)):
+        check(a, b, 1e-12)
+    to, pto = po.inverse_dynamics_host(Z, 24, 7)
+    th, pth = ph.inverse_dynamics_host(Z, 24, 7)
+    check(th, to)
+    check(pth, pto)
+    assert np.array_equal(pth == 0.0, pto == 0.0)  # the block structure of pq_pz (columns outside the sample's piece) is exact
+
+
+@pytest.mark.parametrize("fixed_ends,gripper,degree", [(True, False, 3), (False, True, 2), (True, True, 5)])
+def test_kinova_longer_horizon_rows(oracle, hip, kinova, fixed_ends, gripper, degree):
+    rng = np.random.default_rng(23 + degree)
+    q0, qT = (rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)) if fixed_ends else (None, None)
+    N = 4 * (degree + 1)
+    po, ph, keep = both(oracle, hip, lambda api, k: longer_horizon_problem(api, kinova, k, degree, N, 3.0, q0, qT, gripper=gripper))
+    ns = 20 if gripper else 17
+    assert po.n == ph.n == 21 * degree + (0 if fixed_ends else 14)
+    assert po.m == ph.m == N * (21 + ns) and po.block_offsets == ph.block_offsets
+    assert np.array_equal(po.bounds()[0], ph.bounds()[0]) and np.array_equal(po.bounds()[1], ph.bounds()[1])
+    Z = rng.uniform(-1, 1, (5, po.n))
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    Gh2, _ = ph.eval_host(Z, A.EVAL_G)  # eval_g alone
+    assert np.array_equal(Gh2, Gh)
+    # ragged batch / no obstacles
+    none = (np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)))
+    po, ph, keep = both(oracle, hip, lambda api, k: longer_horizon_problem(api, kinova, k, degree, N, 3.0, q0, qT, boxes=none))
+    Go, Jo = po.eval_host(Z[:1])
+    Gh, Jh = ph.eval_host(Z[:1])
+    check(Gh, Go)
+    check(Jh, Jo)
+    with pytest.raises(A.RaptorError):
+        ph.eval_h_host(Z[:1], np.zeros((1, ph.m)))  # exact Hessians are not built for this trajectory class

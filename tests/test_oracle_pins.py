@@ -346,3 +346,51 @@ def test_dual_kinova_arm_arm_rows(oracle, kinova):
     assert np.all(Gs.reshape(2, N, 4)[:, :, [0, 3]] <= off + 1e-12)
     with pytest.raises(A.RaptorInvalidArgument):
         oracle.dual_kinova_arm_arm_host(p1, H.kinova_problem(oracle, m2, keep, N=N + 1), Z, N)
+
+
+def piecewise_problem(api, model, keep, degree=3, N=24, T=2.0, q0=None, qT=None):
+    """InverseDynamics over PiecewiseBezierCurves(T, N, nv, degree, q0, qT) (KinovaLongerHorizonOptimizer.cpp:39-47)."""
+    mh = api.model_create(model)
+    keep.append(mh)
+    t = A.make_traj_desc(keep, A.TRAJ_PIECEWISE_BEZIER, T, N, model.nv, degree, A.TIME_UNIFORM, q0=q0, qT=qT)
+    return A.ProblemHandle.inverse_dynamics(api, mh, t)
+
+
+@pytest.mark.parametrize("fixed_ends", [True, False])
+def test_piecewise_bezier_against_scipy_bpoly(oracle, kinova, fixed_ends):
+    """PiecewiseBezierCurves.cpp:52-255 against an independent construction: scipy's BPoly.from_derivatives builds the quintic
+    pieces from (q, q_d, q_dd) at the breakpoints k T / (degree + 1); zero velocity / acceleration at both ends (:91-92, 111-112)."""
+    from scipy.interpolate import BPoly
+
+    keep = []
+    degree, N, T = 3, 24, 2.0
+    rng = np.random.default_rng(13)
+    q0, qT = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    p = piecewise_problem(oracle, kinova, keep, degree, N, T, q0 if fixed_ends else None, qT if fixed_ends else None)
+    assert p.n == 7 * degree * 3 + (0 if fixed_ends else 14)  # :34-45
+    z = rng.uniform(-1, 1, p.n)
+    if not fixed_ends:
+        q0, qT = z[63:70], z[70:77]  # begin position first, then the end position
+    q, qd, qdd = (a[0] for a in p.trajectory_host(z, N, 7))
+    ts = np.linspace(0.0, T, N)
+    xi = np.arange(degree + 2) * T / (degree + 1)
+    for j in range(7):
+        yi = [[q0[j], 0.0, 0.0]] + [[z[k * 21 + j], z[k * 21 + 7 + j], z[k * 21 + 14 + j]] for k in range(degree)] + [[qT[j], 0.0, 0.0]]
+        bp = BPoly.from_derivatives(xi, yi)
+        assert np.abs(q[:, j] - bp(ts)).max() < 1e-12
+        assert np.abs(qd[:, j] - bp.derivative(1)(ts)).max() < 1e-11
+        assert np.abs(qdd[:, j] - bp.derivative(2)(ts)).max() < 1e-10
+    # pq_pz through TorqueLimits' chain: the reference's finite-difference recipe (TestInverseDynamics.cpp:13-46)
+    tau, ptau = p.inverse_dynamics_host(z, N, 7)
+    h = 1e-6
+    for c in rng.choice(p.n, 12, replace=False):
+        e = np.zeros(p.n)
+        e[c] = h
+        num = (p.inverse_dynamics_host(z + e, N, 7, False)[0] - p.inverse_dynamics_host(z - e, N, 7, False)[0])[0] / (2 * h)
+        assert np.abs(ptau[0, :, :, c] - num).max() < 1e-5
+
+
+def test_piecewise_bezier_errors(oracle, kinova):
+    keep = []
+    with pytest.raises(A.RaptorInvalidArgument):
+        piecewise_problem(oracle, kinova, keep, degree=3, N=25)  # N must be a multiple of degree + 1 (:18-20)
