@@ -328,13 +328,19 @@ int raptor_profile_end(raptor_problem* problem, int* evaluations, double* id_ms_
  *   RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY      MinimizeInitialVelocity::compute     Costs/src/MinimizeInitialVelocity.cpp:10-41
  *   RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION  MinimizeInitialAcceleration::compute (same form on q_dd(0))
  * F [B][num_costs] = the members `f`, GRAD [B][num_costs][n] = `grad_f` (NULL: compute_derivatives = false).  The weighted sum
- * of Optimizer::eval_f / eval_grad_f (Optimization/src/Optimizer.cpp:201-295) stays with the caller.  Legged / Digit
- * problems only (the torques are ConstrainedInverseDynamics::tau).
+ * of Optimizer::eval_f / eval_grad_f (Optimization/src/Optimizer.cpp:201-295) stays with the caller.  These four: legged /
+ * Digit problems only (the torques are ConstrainedInverseDynamics::tau).
  */
 #define RAPTOR_COST_MINIMIZE_POWER 0
 #define RAPTOR_COST_MINIMIZE_TORQUE 1
 #define RAPTOR_COST_MINIMIZE_INITIAL_VELOCITY 2
 #define RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION 3
+/* the costs of KinovaLongerHorizonOptimizer (KinovaLongerHorizonOptimizer.cpp:114-119), trajectory only, any problem kind;
+ * not to be mixed with the four above in one call:
+ *   RAPTOR_COST_MINIMIZE_PATH_LENGTH  MinimizePathLength::compute  Costs/src/MinimizePathLength.cpp:10-61
+ *   RAPTOR_COST_MINIMIZE_JERK         MinimizeJerk::compute        Costs/src/MinimizeJerk.cpp:10-61      */
+#define RAPTOR_COST_MINIMIZE_PATH_LENGTH 4
+#define RAPTOR_COST_MINIMIZE_JERK 5
 int raptor_eval_costs(raptor_problem* problem, const double* d_Z, int B, int num_costs, const int* kinds, double* d_F,
                       double* d_GRAD, void* stream);
 int raptor_eval_costs_host(raptor_problem* problem, const double* Z, int B, int num_costs, const int* kinds, double* F,

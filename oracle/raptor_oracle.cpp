@@ -1718,6 +1718,32 @@ static void cost_compute(Problem& p, int kind, const double* z, bool deriv, doub
                 grad[c] = s / nrm;
             }
         }
+    } else if (kind == RAPTOR_COST_MINIMIZE_PATH_LENGTH || kind == RAPTOR_COST_MINIMIZE_JERK) {
+        // MinimizePathLength.cpp:10-61 on q, MinimizeJerk.cpp:10-61 on q_dd: sum of 0.5 |x(i+1) - x(i)|^2 over the samples, / N
+        p.traj.compute(z, deriv);
+        const bool jerk = kind == RAPTOR_COST_MINIMIZE_JERK;
+        for (int i = 0; i < N - 1; i++) {
+            const VecX& x1 = jerk ? p.traj.q_dd[i] : p.traj.q[i];
+            const VecX& x2 = jerk ? p.traj.q_dd[i + 1] : p.traj.q[i + 1];
+            VecX diff(Nact);
+            double dd = 0;
+            for (int j = 0; j < Nact; j++) {
+                diff[j] = x2[j] - x1[j];
+                dd += diff[j] * diff[j];
+            }
+            f += 0.5 * dd;
+            if (deriv) {
+                const MatX& P1 = jerk ? p.traj.pq_dd_pz[i] : p.traj.pq_pz[i];
+                const MatX& P2 = jerk ? p.traj.pq_dd_pz[i + 1] : p.traj.pq_pz[i + 1];
+                for (int c = 0; c < V; c++) {
+                    double s = 0;
+                    for (int j = 0; j < Nact; j++) s += diff[j] * (P2(j, c) - P1(j, c));
+                    grad[c] += s;
+                }
+            }
+        }
+        f /= N;
+        for (double& g : grad) g /= N;
     } else {
         throw std::invalid_argument("unknown cost kind");
     }

@@ -30,6 +30,8 @@ COST_MINIMIZE_POWER = 0
 COST_MINIMIZE_TORQUE = 1
 COST_MINIMIZE_INITIAL_VELOCITY = 2
 COST_MINIMIZE_INITIAL_ACCELERATION = 3
+COST_MINIMIZE_PATH_LENGTH = 4
+COST_MINIMIZE_JERK = 5
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

@@ -1462,11 +1462,26 @@ int raptor_eval_costs(raptor_problem* p, const double* d_Z, int B, int num_costs
     API_TRY
     if (!p || !kinds || (B > 0 && (!d_Z || !d_F))) throw std::invalid_argument("null argument");
     if (B < 0 || num_costs < 0) throw std::invalid_argument("negative size");
-    if (p->kind != 2) throw std::invalid_argument("costs: the problem has no ConstrainedInverseDynamics");
-    for (int k = 0; k < num_costs; k++)
-        if (kinds[k] < 0 || kinds[k] > RAPTOR_COST_MINIMIZE_INITIAL_ACCELERATION) throw std::invalid_argument("unknown cost kind");
+    int traj_only = 0;
+    for (int k = 0; k < num_costs; k++) {
+        if (kinds[k] < 0 || kinds[k] > RAPTOR_COST_MINIMIZE_JERK) throw std::invalid_argument("unknown cost kind");
+        if (kinds[k] >= RAPTOR_COST_MINIMIZE_PATH_LENGTH) traj_only++;
+    }
+    if (traj_only != 0 && traj_only != num_costs) throw unsupported_error("costs: path length / jerk cannot share a call with the torque-based costs");
+    if (traj_only == 0 && p->kind != 2) throw std::invalid_argument("costs: the problem has no ConstrainedInverseDynamics");
     if (B == 0 || num_costs == 0) return RAPTOR_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (traj_only) {  // MinimizePathLength / MinimizeJerk: functions of the trajectory alone
+        const size_t lds_bytes = ((size_t)p->htraj.N * p->htraj.Nact + RAPTOR_BLOCK) * sizeof(double);
+        if (lds_bytes > 64 * 1024) throw unsupported_error("costs: N * Nact too large for the trajectory-cost kernel");
+        if ((long long)B * num_costs > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+        p->d_kinds.ensure(num_costs);
+        HIP_CHECK(hipMemcpyAsync(p->d_kinds.p, kinds, num_costs * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(traj_cost_kernel, dim3((unsigned)(B * num_costs)), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_traj.p,
+                           p->d_basis.p, p->d_wsum.p, d_Z, p->layout.n, num_costs, p->d_kinds.p, d_F, d_GRAD);
+        HIP_CHECK(hipGetLastError());
+        return RAPTOR_OK;
+    }
     launch_legged_core(*p, d_Z, B, nullptr, d_GRAD != nullptr, st);
     p->d_kinds.ensure(num_costs);
     HIP_CHECK(hipMemcpyAsync(p->d_kinds.p, kinds, num_costs * sizeof(int), hipMemcpyHostToDevice, st));

@@ -105,4 +105,61 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void sphere_rows_kernel(
     }
 }
 
+// MinimizePathLength / MinimizeJerk (Costs/src/MinimizePathLength.cpp:10-61, MinimizeJerk.cpp:10-61) for any trajectory whose
+// columns move one joint each:  f = (1/N) sum_i 0.5 |x(i+1) - x(i)|^2,  x = q or q_dd;
+// grad_f(c) = (1/N) sum_i (x(i+1) - x(i))_{joint(c)} (w(i+1, c) - w(i, c)),  w = the column's pq_pz / pq_dd_pz entry.
+// One workgroup per (decision vector, cost): the N x Nact values go to LDS once, lanes then own columns; fixed summation order.
+__global__ __launch_bounds__(RAPTOR_BLOCK) void traj_cost_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                                                                  const double* __restrict__ wsum, const double* __restrict__ Z,
+                                                                  const int n, const int num_costs, const int* __restrict__ kinds,
+                                                                  double* __restrict__ F, double* __restrict__ GRAD) {
+    extern __shared__ double lx[];  // [N][Nact], then 256 partial sums
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x / num_costs;
+    const int k = blockIdx.x - (int)(b * num_costs);
+    const bool jerk = kinds[k] == RAPTOR_COST_MINIMIZE_JERK;
+    // n >= V: the legged problems append variables the trajectory ignores (TalosSingleStepOptimizer.cpp:50-51)
+    const int N = T->N, Nact = T->Nact;
+    const int V = (T->type == RAPTOR_TRAJ_BEZIER || T->type == RAPTOR_TRAJ_POLYNOMIAL) ? T->K * Nact : T->varLength;
+    const double* z = Z + b * n;
+    for (int idx = tid; idx < N * Nact; idx += RAPTOR_BLOCK) {
+        const int i = idx / Nact, j = idx - i * Nact;
+        double q, qd, qdd;
+        traj_joint(T, basis, z, i, j, q, qd, qdd);
+        lx[idx] = jerk ? qdd : q;
+    }
+    __syncthreads();
+    double* red = lx + N * Nact;
+    double part = 0.0;
+    for (int idx = tid; idx < (N - 1) * Nact; idx += RAPTOR_BLOCK) {
+        const double d = lx[idx + Nact] - lx[idx];
+        part += 0.5 * d * d;
+    }
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int t = 0; t < RAPTOR_BLOCK; t++) s += red[t];
+        F[b * num_costs + k] = s / N;
+    }
+    if (GRAD == nullptr) return;
+    for (int c = tid; c < n; c += RAPTOR_BLOCK) {
+        if (c >= V) {
+            GRAD[(b * num_costs + k) * n + c] = 0.0;
+            continue;
+        }
+        int jd;
+        double w0, w1, w2, p0, p1, p2;
+        column_direction(T, basis, wsum, 0, c, jd, p0, p1, p2);
+        double s = 0.0;
+        for (int i = 0; i < N - 1; i++) {
+            column_direction(T, basis, wsum, i + 1, c, jd, w0, w1, w2);
+            s += (lx[(i + 1) * Nact + jd] - lx[i * Nact + jd]) * (jerk ? (w2 - p2) : (w0 - p0));
+            p0 = w0;
+            p2 = w2;
+        }
+        GRAD[(b * num_costs + k) * n + c] = s / N;
+    }
+}
+
 #endif

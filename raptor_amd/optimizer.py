@@ -366,3 +366,23 @@ class SingleStepOptimizer(Optimizer):
             for k, w in enumerate(self.costsWeightVec_):
                 grad += w * GR[0, k]
         return float(obj), grad
+
+
+class KinovaLongerHorizonOptimizer(SingleStepOptimizer):
+    """KinovaLongerHorizonOptimizer::set_parameters (KinovaLongerHorizonOptimizer.cpp:18-122): PiecewiseBezierCurves, the four Kinova
+    blocks, MinimizePathLength (20) + MinimizeJerk (2).  The reference sets enable_hessian; exact Hessians are not built for this
+    trajectory class here, so the shell reports eval_h == False and a solver falls back to a quasi-Newton approximation
+    (Ipopt: hessian_approximation limited-memory)."""
+
+    def __init__(self, api, model_handle, x0, T, N, degree, q0, qT, boxCenters, boxOrientation, boxSize,
+                 joint_limits_buffer=None, velocity_limits_buffer=None, torque_limits_buffer=None,
+                 include_gripper_or_not=False, collision_buffer=0.0):
+        self._keep = []
+        traj = A.make_traj_desc(self._keep, A.TRAJ_PIECEWISE_BEZIER, T, N, 7, degree, A.TIME_UNIFORM, q0=q0, qT=qT)
+        prob = A.ProblemHandle.kinova(api, model_handle, traj, boxCenters, boxOrientation, boxSize,
+                                      joint_limits_buffer=joint_limits_buffer, velocity_limits_buffer=velocity_limits_buffer,
+                                      torque_limits_buffer=torque_limits_buffer, include_gripper=include_gripper_or_not,
+                                      collision_buffer=collision_buffer)
+        super().__init__(prob, x0, KinovaOptimizer.NAMES,
+                         costs=((A.COST_MINIMIZE_PATH_LENGTH, 20.0, "minimize path length"),
+                                (A.COST_MINIMIZE_JERK, 2.0, "minimize jerk for smoothness")))

@@ -721,3 +721,23 @@ def test_kinova_longer_horizon_rows(oracle, hip, kinova, fixed_ends, gripper, de
     check(Jh, Jo)
     with pytest.raises(A.RaptorError):
         ph.eval_h_host(Z[:1], np.zeros((1, ph.m)))  # exact Hessians are not built for this trajectory class
+
+
+def test_path_length_and_jerk_costs_gpu(oracle, hip, kinova):
+    """KinovaLongerHorizonOptimizer's costs (MinimizePathLength, MinimizeJerk) on the three trajectory layouts."""
+    kinds = [A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK]
+    rng = np.random.default_rng(29)
+    builders = [lambda api, k: longer_horizon_problem(api, kinova, k, 3, 24, 3.0, rng.uniform(-1, 1, 7) * 0 + 0.3, None),
+                lambda api, k: H.kinova_problem(api, kinova, k, N=16),
+                lambda api, k: H.legged_problem(api, "g1", k, N=6)[0]]
+    for build in builders:
+        po, ph, keep = both(oracle, hip, build)
+        Z = 0.5 * rng.uniform(-1, 1, (3, po.n))
+        Fo, Go = po.costs_host(Z, kinds)
+        Fh, Gh = ph.costs_host(Z, kinds)
+        check(Fh, Fo, 1e-12)
+        check(Gh, Go, 1e-12)
+        Fh2, none = ph.costs_host(Z, kinds[::-1], derivatives=False)
+        assert none is None and np.array_equal(Fh2, Fh[:, ::-1])
+    with pytest.raises(A.RaptorError):
+        ph.costs_host(Z, [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_JERK])  # the two families do not share a call

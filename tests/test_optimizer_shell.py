@@ -134,3 +134,49 @@ def test_solve_on_the_gpu_matches_the_oracle_run(oracle, hip, kinova):
     oh, rh, _ = solve_kinova(hip, kinova, keep)
     assert oh.ifFeasible and abs(oh.obj_value_copy - oo.obj_value_copy) < 1e-8
     assert np.abs(oh.solution - oo.solution).max() < 1e-5
+
+
+def longer_horizon_optimizer(api, kinova, keep, degree=2, N=12):
+    mh = api.model_create(kinova)
+    keep.append(mh)
+    c, rpy, size = H.example_boxes()
+    q0, qT = np.zeros(7), np.full(7, 0.4)
+    # straight line from q0 to qT as the initial guess (KinovaLongerHorizonPybindWrapper.cpp:143-149)
+    x0 = np.zeros(21 * degree)
+    for k in range(degree):
+        x0[k * 21:k * 21 + 7] = q0 + (qT - q0) * (k + 1) / (degree + 1)
+    return O.KinovaLongerHorizonOptimizer(api, mh, x0, 3.0, N, degree, q0, qT, c, rpy, size), q0, qT
+
+
+def test_longer_horizon_shell(oracle, kinova):
+    """KinovaLongerHorizonOptimizer.cpp:18-122: four blocks over PiecewiseBezierCurves, 20 x path length + 2 x jerk."""
+    keep = []
+    opt, q0, qT = longer_horizon_optimizer(oracle, kinova, keep)
+    n, m, _, _ = opt.get_nlp_info()
+    assert (n, m) == (42, 12 * 38)
+    opt.get_bounds_info(n, m)
+    x = opt.get_starting_point(n)
+    F, GR = opt.problem.costs_host(x, [A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK])
+    assert opt.eval_f(n, x, True) == pytest.approx(20.0 * F[0, 0] + 2.0 * F[0, 1], rel=1e-14)
+    assert np.allclose(opt.eval_grad_f(n, x, False), 20.0 * GR[0, 0] + 2.0 * GR[0, 1], rtol=1e-14, atol=0)
+    assert opt.eval_h(n, x, False, 1.0, m, np.zeros(m), True) is False
+    f0 = opt.eval_f(n, x, True)
+    res = opt.solve(max_iter=25)
+    assert opt.ifFeasible and opt.obj_value_copy < f0
+    q, _, _ = opt.problem.trajectory_host(opt.solution, 12, 7)
+    assert np.abs(q[0, 0] - q0).max() < 1e-13 and np.abs(q[0, -1] - qT).max() < 1e-13  # the ends are pinned by construction
+
+
+@pytest.mark.gpu
+def test_longer_horizon_shell_on_the_gpu(oracle, hip, kinova):
+    keep = []
+    oo, _, _ = longer_horizon_optimizer(oracle, kinova, keep)
+    oh, _, _ = longer_horizon_optimizer(hip, kinova, keep)
+    for o in (oo, oh):
+        n, m, _, _ = o.get_nlp_info()
+        o.get_bounds_info(n, m)
+    x = oo.get_starting_point(n) + 0.05 * np.random.default_rng(2).uniform(-1, 1, n)
+    assert abs(oh.eval_f(n, x, True) - oo.eval_f(n, x, True)) < 1e-11
+    assert np.abs(oh.eval_grad_f(n, x, False) - oo.eval_grad_f(n, x, False)).max() < 1e-11
+    assert H.rel_err(oh.eval_g(n, x, False, m), oo.eval_g(n, x, False, m)) < 1e-9
+    assert H.rel_err(oh.eval_jac_g(n, x, False, m), oo.eval_jac_g(n, x, False, m)) < 1e-9

@@ -394,3 +394,22 @@ def test_piecewise_bezier_errors(oracle, kinova):
     keep = []
     with pytest.raises(A.RaptorInvalidArgument):
         piecewise_problem(oracle, kinova, keep, degree=3, N=25)  # N must be a multiple of degree + 1 (:18-20)
+
+
+def test_path_length_and_jerk_costs(oracle, kinova):
+    """MinimizePathLength.cpp:10-61 / MinimizeJerk.cpp:10-61 from the trajectory samples (numpy) and finite differences."""
+    keep = []
+    rng = np.random.default_rng(19)
+    p = piecewise_problem(oracle, kinova, keep, 3, 24, 2.0, rng.uniform(-1, 1, 7), None)
+    z = rng.uniform(-1, 1, p.n)
+    kinds = [A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK]
+    F, GR = p.costs_host(z, kinds)
+    q, _, qdd = (a[0] for a in p.trajectory_host(z, 24, 7))
+    assert F[0, 0] == pytest.approx(0.5 * (np.diff(q, axis=0) ** 2).sum() / 24, rel=1e-13)
+    assert F[0, 1] == pytest.approx(0.5 * (np.diff(qdd, axis=0) ** 2).sum() / 24, rel=1e-13)
+    h = 1e-6
+    for c in range(p.n):
+        e = np.zeros(p.n)
+        e[c] = h
+        num = (p.costs_host(z + e, kinds, False)[0] - p.costs_host(z - e, kinds, False)[0])[0] / (2 * h)
+        assert np.abs(num - GR[0, :, c]).max() < 1e-5 * max(1.0, np.abs(GR[0, :, c]).max())
