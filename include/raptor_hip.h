@@ -303,6 +303,7 @@ int raptor_step_link_eval_batch_host(raptor_problem* curr, raptor_problem* next,
  * the same N, per sample the four pairs (tapered capsule 1, 2 of robot 1) x (tapered capsule 1, 2 of robot 2), each capsule
  * spanned by two collision spheres (KinovaCustomizedConstraints.h:58-63; the gripper extends the last capsule).
  *   Z [B][numVars1 + numVars2] (robot 1's variables first) -> G [B][N*4], JAC [B][N*4][numVars1 + numVars2] row-major.
+ * The members may be ARMOUR_BEZIER or PIECEWISE_BEZIER problems (the reference's members are KinovaLongerHorizonOptimizers, :41-42).
  * The two robots' own blocks come from raptor_eval_batch on each problem, as the reference calls the two KinovaOptimizers.
  */
 int raptor_dual_kinova_arm_arm_batch(raptor_problem* problem1, raptor_problem* problem2, const double* d_Z, int B,

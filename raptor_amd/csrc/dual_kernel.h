@@ -15,11 +15,13 @@ struct DualCapsules {
     int ids[2][2][2];  // [robot][capsule 1, 2][first, second] sphere index
 };
 
-// centres of two spheres of one arm and their Jacobians w.r.t. that arm's 7 ArmourBezier variables (pq_pz = w0 * identity)
+// centres of two spheres of one arm and their Jacobians w.r.t. that arm's V decision variables: column c moves joint c mod 7 with
+// weight pq_pz(c mod 7, c) -- ArmourBezierCurves (V = 7, w0 * identity) and PiecewiseBezierCurves (the reference's
+// DualKinovaOptimizer members are KinovaLongerHorizonOptimizers: DualKinovaOptimizer.cpp:41-42)
 RD void kinova_two_spheres(const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
                            const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const double* __restrict__ z,
                            const int i, const int sa, const int sb, double* __restrict__ Pout, double* __restrict__ dPout,
-                           const int F, const int col0, double* __restrict__ Rout) {
+                           const int F, const int col0, const int zero0, const int zeroV, double* __restrict__ Rout) {
     constexpr int NV = 7;
     const int ja = S->joint_id[sa], jb = S->joint_id[sb];  // Pinocchio joint ids (1-based)
     M3 Rw;
@@ -47,21 +49,23 @@ RD void kinova_two_spheres(const DevModel* __restrict__ M, const DevTraj* __rest
     Rout[0] = S->radius[sa];
     Rout[1] = S->radius[sb];
     if (dPout == nullptr) return;
-    const double w0 = wsum[i * 3];
+    const int V = T->varLength;
 #pragma unroll
-    for (int c = 0; c < NV; c++) {
-        // d centre / d q_c = omega_c x (centre - o_c) = s.a x centre + s.l  (world-origin joint axis), for joints up to the sphere's link
-        const V3 da = (c < ja) ? (cross(sj[c].a, ca) + sj[c].l) * w0 : v3(0, 0, 0);
-        const V3 db = (c < jb) ? (cross(sj[c].a, cb) + sj[c].l) * w0 : v3(0, 0, 0);
-        dPout[0 * F + col0 + c] = da.x; dPout[1 * F + col0 + c] = da.y; dPout[2 * F + col0 + c] = da.z;
-        dPout[3 * F + col0 + c] = db.x; dPout[4 * F + col0 + c] = db.y; dPout[5 * F + col0 + c] = db.z;
+    for (int j = 0; j < NV; j++) {
+        // d centre / d q_j = omega_j x (centre - o_j) = s.a x centre + s.l  (world-origin joint axis), for joints up to the sphere's link
+        const V3 dja = (j < ja) ? (cross(sj[j].a, ca) + sj[j].l) : v3(0, 0, 0);
+        const V3 djb = (j < jb) ? (cross(sj[j].a, cb) + sj[j].l) : v3(0, 0, 0);
+        for (int c = j; c < V; c += NV) {
+            int jd;
+            double w0, w1, w2;
+            column_direction(T, basis, wsum, i, c, jd, w0, w1, w2);
+            dPout[0 * F + col0 + c] = dja.x * w0; dPout[1 * F + col0 + c] = dja.y * w0; dPout[2 * F + col0 + c] = dja.z * w0;
+            dPout[3 * F + col0 + c] = djb.x * w0; dPout[4 * F + col0 + c] = djb.y * w0; dPout[5 * F + col0 + c] = djb.z * w0;
+        }
     }
     // the other robot's columns
-    const int z0 = (col0 == 0) ? NV : 0;
-#pragma unroll
     for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < NV; c++) dPout[r * F + z0 + c] = 0.0;
+        for (int c = 0; c < zeroV; c++) dPout[r * F + zero0 + c] = 0.0;
 }
 
 __global__ __launch_bounds__(64) void dual_kinova_points_kernel(
@@ -79,13 +83,14 @@ __global__ __launch_bounds__(64) void dual_kinova_points_kernel(
     const int i = (int)(e % N);
     const long long b = e / N;
     const int j1 = j >> 1, j2 = j & 1;  // j counts (j1, j2) with j2 fastest (DualKinovaOptimizer.cpp:283-285)
-    const double* z = Z + b * 14;
+    const int n1 = T1->varLength, n2 = T2->varLength, F = n1 + n2;
+    const double* z = Z + b * F;
     double* Pp = P + (size_t)idx * 12;
-    double* dp = dP ? dP + (size_t)idx * 12 * 14 : nullptr;
+    double* dp = dP ? dP + (size_t)idx * 12 * F : nullptr;
     double* Rp = R + (size_t)idx * 4;
-    kinova_two_spheres(M1, T1, basis1, wsum1, S1, z, i, caps.ids[0][j1][0], caps.ids[0][j1][1], Pp, dp, 14, 0, Rp);
-    kinova_two_spheres(M2, T2, basis2, wsum2, S2, z + 7, i, caps.ids[1][j2][0], caps.ids[1][j2][1], Pp + 6, dp ? dp + 6 * 14 : nullptr,
-                       14, 7, Rp + 2);
+    kinova_two_spheres(M1, T1, basis1, wsum1, S1, z, i, caps.ids[0][j1][0], caps.ids[0][j1][1], Pp, dp, F, 0, n1, n2, Rp);
+    kinova_two_spheres(M2, T2, basis2, wsum2, S2, z + n1, i, caps.ids[1][j2][0], caps.ids[1][j2][1], Pp + 6, dp ? dp + 6 * F : nullptr,
+                       F, n1, 0, n1, Rp + 2);
 }
 
 #endif

@@ -1666,7 +1666,8 @@ static void step_link_device(raptor_problem& pc, raptor_problem& pn, const doubl
 // DualKinovaOptimizer.cpp:269-305, 449-510
 static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const double* dZ, int B, unsigned flags, double* dG,
                                 double* dJ, hipStream_t st) {
-    if (p1.kind != 1 || p2.kind != 1) throw std::invalid_argument("dual Kinova: both problems must be Kinova problems");
+    if ((p1.kind != 1 && p1.kind != 3) || (p2.kind != 1 && p2.kind != 3))
+        throw std::invalid_argument("dual Kinova: both problems must be Kinova problems");
     if (p1.htraj.N != p2.htraj.N) throw std::invalid_argument("dual Kinova: the two trajectories must have the same N");
     if (!(flags & (RAPTOR_EVAL_G | RAPTOR_EVAL_JAC))) throw std::invalid_argument("flags: nothing to evaluate");
     const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
@@ -1683,9 +1684,11 @@ static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const do
         caps.ids[r][1][0] = 12; caps.ids[r][1][1] = pr[r]->hspheres.num_spheres >= 20 ? 19 : 13;
     }
     const long long total = (long long)B * p1.htraj.N * 4;
-    const int CH = 32768;  // pairs per pass: bounds the staging area (12 + 168 + 4 doubles per pair)
+    const int F = p1.layout.n + p2.layout.n;
+    // pairs per pass: bounds the staging area (12 + 12 F + 4 doubles per pair; 32768 pairs at F = 14, fewer for wider problems)
+    const int CH = std::max(256, std::min(32768, (int)((32768LL * 12 * 14) / (12LL * F))));
     p1.s_a.ensure((size_t)CH * 12);
-    if (jac) p1.s_b.ensure((size_t)CH * 12 * 14);
+    if (jac) p1.s_b.ensure((size_t)CH * 12 * F);
     p1.s_c.ensure((size_t)CH * 5);
     double* dR = p1.s_c.p;
     double* dDist = p1.s_c.p + (size_t)CH * 4;
@@ -1694,8 +1697,8 @@ static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const do
         hipLaunchKernelGGL(dual_kinova_points_kernel, dim3((np + 63) / 64), dim3(64), 0, st, p1.d_model.p, p1.d_traj.p, p1.d_basis.p,
                            p1.d_wsum.p, p1.d_spheres.p, p2.d_model.p, p2.d_traj.p, p2.d_basis.p, p2.d_wsum.p, p2.d_spheres.p, caps, dZ,
                            p0, np, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR);
-        hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(np)), dim3(RAPTOR_BLOCK), 0, st, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR, np, 14,
-                           (flags & RAPTOR_EVAL_G) ? dG + p0 : dDist, jac ? dJ + (size_t)p0 * 14 : nullptr);
+        hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(np)), dim3(RAPTOR_BLOCK), 0, st, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR, np, F,
+                           (flags & RAPTOR_EVAL_G) ? dG + p0 : dDist, jac ? dJ + (size_t)p0 * F : nullptr);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1755,14 +1758,15 @@ int raptor_dual_kinova_arm_arm_batch_host(raptor_problem* p1, raptor_problem* p2
     if ((flags & RAPTOR_EVAL_G) && !G) throw std::invalid_argument("G buffer is null");
     if (B == 0) return RAPTOR_OK;
     const size_t rows = (size_t)p1->htraj.N * 4;
-    p1->s_Z.ensure((size_t)B * 14);
+    const size_t F = (size_t)p1->layout.n + p2->layout.n;  // numVars1 + numVars2
+    p1->s_Z.ensure((size_t)B * F);
     p1->s_G.ensure((size_t)B * rows);
-    if (jac) p1->s_J.ensure((size_t)B * rows * 14);
-    HIP_CHECK(hipMemcpy(p1->s_Z.p, Z, (size_t)B * 14 * sizeof(double), hipMemcpyHostToDevice));
+    if (jac) p1->s_J.ensure((size_t)B * rows * F);
+    HIP_CHECK(hipMemcpy(p1->s_Z.p, Z, (size_t)B * F * sizeof(double), hipMemcpyHostToDevice));
     dual_arm_arm_device(*p1, *p2, p1->s_Z.p, B, flags, p1->s_G.p, jac ? p1->s_J.p : nullptr, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     if (flags & RAPTOR_EVAL_G) HIP_CHECK(hipMemcpy(G, p1->s_G.p, (size_t)B * rows * sizeof(double), hipMemcpyDeviceToHost));
-    if (jac) HIP_CHECK(hipMemcpy(JAC, p1->s_J.p, (size_t)B * rows * 14 * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac) HIP_CHECK(hipMemcpy(JAC, p1->s_J.p, (size_t)B * rows * F * sizeof(double), hipMemcpyDeviceToHost));
     API_CATCH
 }
 

@@ -741,3 +741,34 @@ def test_path_length_and_jerk_costs_gpu(oracle, hip, kinova):
         assert none is None and np.array_equal(Fh2, Fh[:, ::-1])
     with pytest.raises(A.RaptorError):
         ph.costs_host(Z, [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_JERK])  # the two families do not share a call
+
+
+def test_dual_kinova_arm_arm_rows_piecewise(oracle, hip, kinova):
+    """The reference wires DualKinovaOptimizer with KinovaLongerHorizonOptimizer members (DualKinovaOptimizer.cpp:41-42):
+    arm-arm rows over numVars1 + numVars2 = 21 (degree1 + degree2) columns; also a mixed ArmourBezier / piecewise pair."""
+    m2 = kinova.copy()
+    m2.placement_p = m2.placement_p.copy()
+    m2.placement_p[0] = m2.placement_p[0] + np.array([0.55, 0.25, 0.0])
+    rng = np.random.default_rng(37)
+    N = 12
+    q0a, qTa, q0b = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    keep = []
+    mk1 = lambda api: longer_horizon_problem(api, kinova, keep, 2, N, 3.0, q0a, qTa)           # noqa: E731
+    mk2 = lambda api: longer_horizon_problem(api, m2, keep, 3, N, 3.0, q0b, None, gripper=True)  # noqa: E731
+    o1, o2, h1, h2 = mk1(oracle), mk2(oracle), mk1(hip), mk2(hip)
+    assert h1.n + h2.n == 42 + 70
+    Z = 0.7 * rng.uniform(-1, 1, (9, h1.n + h2.n))
+    Go, Jo = oracle.dual_kinova_arm_arm_host(o1, o2, Z, N)
+    Gh, Jh = hip.dual_kinova_arm_arm_host(h1, h2, Z, N)
+    check(Gh, Go)
+    check(Jh, Jo)
+    # the columns of joint 7 never move these capsules (their spheres sit on joints <= 6 or on joint 7's own axis): exact zeros in
+    # the oracle's FK-derivative form, omega x (centre - origin) with parallel operands here
+    untouched = np.abs(Jo).max(axis=(0, 1)) == 0.0
+    assert list(np.flatnonzero(untouched)) == list(range(6, 112, 7)) and np.abs(Jh[:, :, untouched]).max() < 1e-15
+    o3, h3 = H.kinova_problem(oracle, m2, keep, N=N), H.kinova_problem(hip, m2, keep, N=N)
+    Z = 0.7 * rng.uniform(-1, 1, (4, h1.n + 7))
+    Go, Jo = oracle.dual_kinova_arm_arm_host(o1, o3, Z, N)
+    Gh, Jh = hip.dual_kinova_arm_arm_host(h1, h3, Z, N)
+    check(Gh, Go)
+    check(Jh, Jo)
