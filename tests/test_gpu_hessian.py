@@ -80,6 +80,23 @@ def test_eval_h_both_launch_forms(oracle, hip, kinova):
     assert np.array_equal(ph.eval_h_host(Z[3:4], lam[3:4], 1.0), Hs[3:4])  # deterministic, independent of the batch around it
 
 
+def test_eval_h_inside_boxes(oracle, hip, kinova):
+    """Every sphere inside an obstacle: the nearest-face branch (BoxCollisionAvoidance.cpp:252-274), negative distances, one clamped
+    axis; the first-minimum face / box rules must pick the same face as the oracle for the values to agree."""
+    big = (np.array([[0.0, 0.0, 0.5], [0.1, 0.0, 0.4]]), np.array([[0.3, -0.2, 0.5], [0.0, 0.0, 0.0]]), np.array([[3.0, 3.0, 3.0], [2.5, 2.6, 2.7]]))
+    po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=5, boxes=big, gripper=True))
+    rng = np.random.default_rng(51)
+    Z = rng.uniform(-1, 1, (3, 7))
+    lam = np.zeros((3, po.m))
+    lam[:, po.block_offsets[3]:] = rng.uniform(-1, 1, (3, po.m - po.block_offsets[3]))
+    Go, _ = po.eval_host(Z, A.EVAL_G)
+    assert np.all(Go[:, po.block_offsets[3]:] < 0.0)  # inside for every sphere and sample
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, po.eval_host(Z)[1])
+    check(ph.eval_h_host(Z, lam), po.eval_h_host(Z, lam))
+
+
 def test_eval_h_edge_cases(oracle, hip, kinova):
     none = (np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)))
     po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=3, boxes=none))
