@@ -346,6 +346,10 @@ int raptor_eval_costs(raptor_problem* problem, const double* d_Z, int B, int num
                       double* d_GRAD, void* stream);
 int raptor_eval_costs_host(raptor_problem* problem, const double* Z, int B, int num_costs, const int* kinds, double* F,
                            double* GRAD);
+/* Costs::hess_f of MinimizePathLength / MinimizeJerk (MinimizePathLength.cpp:43-52, MinimizeJerk.cpp:43-52) over
+ * PiecewiseBezierCurves: independent of z (the costs are quadratic), upper triangle row by row, [n (n + 1) / 2].  What
+ * Optimizer::eval_hess_f sums with costsWeightVec_ (Optimizer.cpp:298-337) before eval_h scales it by obj_factor. */
+int raptor_cost_hessian_host(raptor_problem* problem, int kind, double* HESS);
 
 /*
  * KinovaOptimizer's objective (Examples/Kinova/CollisionAvoidanceTrajectory/src/KinovaOptimizer.cpp:152-250):
@@ -367,6 +371,8 @@ int raptor_kinova_eval_objective_host(raptor_problem* problem, const double* Z, 
  * (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:375-475) -- as `values`: the upper triangle row by row,
  * iRow = i, jCol = j >= i (:531-538, :621-627).
  *   Z [B][n], obj_factor [B] (NULL: 0 for every z, eval_hess_f is skipped as at :552), lambda [B][m] -> H [B][n (n + 1) / 2]
+ * KinovaLongerHorizonOptimizer problems (PIECEWISE_BEZIER) are evaluated too: obj_factor must be NULL there (that optimizer's
+ * objective is a weighted sum of Costs: the caller adds obj_factor * sum_k weight_k * raptor_cost_hessian_host(k)).
  * Other problem kinds return RAPTOR_ERR_RUNTIME (the reference's eval_h returns false for them, :513-515).
  */
 int raptor_eval_h_batch(raptor_problem* problem, const double* d_Z, int B, const double* d_obj_factor, const double* d_lambda,

@@ -1765,6 +1765,30 @@ int oracle_eval_costs_host(raptor_problem* pr, const double* Z, int B, int num_c
         }
     ORACLE_CATCH
 }
+// Costs::hess_f of MinimizePathLength / MinimizeJerk (MinimizePathLength.cpp:43-52, 56-60; MinimizeJerk.cpp twin): the
+// pq_pz_pz terms of :45-51 are zero matrices for every trajectory class here, so hess_f does not depend on z.
+int oracle_cost_hessian_host(raptor_problem* pr, int kind, double* HESS) {
+    ORACLE_TRY
+    if (!pr || !HESS) throw std::invalid_argument("null argument");
+    if (kind != RAPTOR_COST_MINIMIZE_PATH_LENGTH && kind != RAPTOR_COST_MINIMIZE_JERK)
+        throw std::runtime_error("cost Hessian: MinimizePathLength / MinimizeJerk only");
+    Problem& p = pr->p;
+    const int N = p.traj.N, V = p.traj.varLength;
+    std::vector<double> z(p.n, 0.0);
+    p.traj.compute(z.data(), true);
+    MatX hess(V, V);
+    for (int i = 0; i < N - 1; i++) {
+        const MatX& P1 = (kind == RAPTOR_COST_MINIMIZE_JERK) ? p.traj.pq_dd_pz[i] : p.traj.pq_pz[i];
+        const MatX& P2 = (kind == RAPTOR_COST_MINIMIZE_JERK) ? p.traj.pq_dd_pz[i + 1] : p.traj.pq_pz[i + 1];
+        const MatX d = P2 - P1;
+        hess = hess + d.transpose() * d;  // :43
+    }
+    size_t it = 0;
+    for (int a = 0; a < V; a++)
+        for (int b = a; b < V; b++) HESS[it++] = hess(a, b) / N;  // :59
+    ORACLE_CATCH
+}
+
 int oracle_eval_costs(raptor_problem* pr, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD, void*) {
     return oracle_eval_costs_host(pr, Z, B, num_costs, kinds, F, GRAD);
 }

@@ -227,6 +227,7 @@ EXPORTS = [
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
     "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host", "step_link_eval_batch", "step_link_eval_batch_host",
     "kinova_set_objective", "kinova_eval_objective", "kinova_eval_objective_host", "eval_h_batch", "eval_h_batch_host",
+    "cost_hessian_host",
 ]
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
 DEVICE_ONLY_EXPORTS = ["probe_fill"]
@@ -273,6 +274,7 @@ class CApi:
         f("kinova_eval_objective_host").argtypes = [vp, _dp, C.c_int, _dp, _dp]
         f("eval_h_batch").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
         f("eval_h_batch_host").argtypes = [vp, _dp, C.c_int, _dp, _dp, _dp]
+        f("cost_hessian_host").argtypes = [vp, C.c_int, _dp]
         if prefix == "oracle_":
             f("inverse_dynamics_hessian_host").argtypes = [vp, _dp, C.c_int, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
@@ -513,6 +515,12 @@ class ProblemHandle:
         GR = np.empty((B, len(kk), self.n)) if derivatives else None
         self.api.check(self.api.fn("eval_costs_host")(self.handle, _ptr(Z), B, len(kk), kk.ctypes.data_as(_ip), _ptr(F), _ptr(GR)))
         return F, GR
+
+    def cost_hessian_host(self, kind: int):
+        """Costs::hess_f of MinimizePathLength / MinimizeJerk (constant in z), packed upper triangle [n (n + 1) / 2]."""
+        Hs = np.empty(self.n * (self.n + 1) // 2)
+        self.api.check(self.api.fn("cost_hessian_host")(self.handle, int(kind), _ptr(Hs)))
+        return Hs
 
     # -- queries ---------------------------------------------------------------------------
     def bounds(self):

@@ -1,0 +1,215 @@
+// eval_h for KinovaLongerHorizonOptimizer (PiecewiseBezierCurves): the Lagrangian Hessian over V = 21 degree (+14) variables.
+//     Optimizer::eval_h                                Optimization/src/Optimizer.cpp:499-635
+//     InverseDynamics::compute, compute_hessian        KinematicsDynamics/src/InverseDynamics.cpp:141-171
+//     KinovaCustomizedConstraints, compute_hessian     KinovaCustomizedConstraints.cpp:117-155
+//
+// The trajectory is linear in z and column c moves joint c mod 7 with per-sample weights (w0, w1, w2)(i, c) = the entries of
+// pq_pz / pq_d_pz / pq_dd_pz.  Unlike ArmourBezierCurves the columns of one joint carry DIFFERENT weight triples, so the
+// Hessian is assembled from per-sample second-order blocks of phi = mu^T tau (+ the obstacle distances) in JOINT space,
+//     H(c1, c2) = sum_i  w0 w0' (Pqq + Pobs)(j, j') + w1 w1' Pvv(j, j') + w0 w1' Pqv(j, j') + w1 w0' Pqv(j', j)
+//                      + w0 w2' Pqa(j, j') + w2 w0' Pqa(j', j),            j = c1 mod 7, j' = c2 mod 7
+// (tau is linear in q_dd and its q_dd coefficient does not depend on q_d: no vv-a, a-a blocks).
+//   kernel 1 (kinova_hess_blocks_kernel): the 154 block entries per sample by the hyper-dual forward recursion of
+//     kinova_hess_kernel.h with UNIT seeds -- an item is (joint j1 <= j2, kind of j1's seed, kind of j2's seed), a wavefront
+//     owns an item, lanes = samples -- plus the 28 obstacle entries (a wavefront per sphere); Phi[b][182][N], sample-minor;
+//   kernel 2 (kinova_hess_contract_kernel): one workgroup per z, a thread per (c1 <= c2), fixed summation order over samples.
+#ifndef RAPTOR_KINOVA_HESS_BLOCKS_KERNEL_H
+#define RAPTOR_KINOVA_HESS_BLOCKS_KERNEL_H
+
+#include "kinova_hess_kernel.h"
+
+#define HB_QQ 0      // Phi block offsets: qq (28, upper triangle), vv (28), qv (49: [jq][jv]), qa (49: [jq][ja]), obstacles (28)
+#define HB_VV 28
+#define HB_QV 56
+#define HB_QA 105
+#define HB_OBS 154
+#define HB_NI 182
+#define HB_MAX_ITEMS 48  // per wavefront (154 items dealt to four)
+
+// item code: j1 | j2 << 3 | k1 << 6 | k2 << 8 | out << 10   (j1 <= j2 joints, k = 0: q, 1: q_d, 2: q_dd seed, out = Phi row)
+struct DevHessItems {
+    int count[H_WAVES];
+    int code[H_WAVES][HB_MAX_ITEMS];
+};
+
+__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
+    const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
+    const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
+    const DevHessItems* __restrict__ items, const double* __restrict__ Z, const double* __restrict__ lambda,
+    double* __restrict__ Phi) {
+    __shared__ double lds[HL_ACC + H_WAVES * H_PAIRS * H_CH];
+    constexpr int NV = 7;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long b = blockIdx.x;
+    const int N = T->N;
+    const int ns = S->num_spheres;
+    const int O = S->num_obstacles;
+    const double* z = Z + b * (long long)L.n;
+    const double* lam = lambda + b * (long long)L.m;
+    double* phi = Phi + b * (long long)HB_NI * N;
+
+#pragma unroll 1
+    for (int i0 = 0; i0 < N; i0 += H_CH) {
+        for (int idx = tid; idx < H_CH * NV; idx += RAPTOR_BLOCK) {
+            const int s = idx & (H_CH - 1), j = idx >> 6;
+            const int i = min(i0 + s, N - 1);
+            double q, qd, qdd, sq, cq;
+            traj_joint(T, basis, z, i, j, q, qd, qdd);
+            sincos(q, &sq, &cq);
+            double* x = lds + HL_X + (j * 5) * H_CH + s;
+            x[0] = qd; x[H_CH] = qdd; x[2 * H_CH] = cq; x[3 * H_CH] = sq; x[4 * H_CH] = q;
+            lds[HL_MU + j * H_CH + s] = (i0 + s < N) ? lam[L.off_tau + i * NV + j] : 0.0;
+        }
+        __syncthreads();
+        const bool live = (i0 + lane) < N;
+
+        if (wave == 0 && O > 0) {  // world-frame joint axes / origins and sphere-link poses, lane = sample
+            M3 Rw;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            V3 ow = v3(0, 0, 0);
+#pragma unroll 1
+            for (int l = 0; l < NV; l++) {
+                const double* x = lds + HL_X + (l * 5) * H_CH + lane;
+                const M3 A = mul(Rw, M->plR[l]);
+                V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+                M3 R;
+                SV s;
+                joint_world(M->jtype[l], x[4 * H_CH], x[2 * H_CH], x[3 * H_CH], A, R, o, s);
+                Rw = R;
+                ow = o;
+                double* wv = lds + HL_W + (l * 6) * H_CH + lane;
+                wv[0] = s.a.x; wv[H_CH] = s.a.y; wv[2 * H_CH] = s.a.z;
+                wv[3 * H_CH] = ow.x; wv[4 * H_CH] = ow.y; wv[5 * H_CH] = ow.z;
+                const int slot = S->ro_slot[l];
+                if (slot >= 0) {
+                    double* ro = lds + HL_RO + (slot * 12) * H_CH + lane;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) ro[k * H_CH] = Rw.m[k];
+                    ro[9 * H_CH] = ow.x; ro[10 * H_CH] = ow.y; ro[11 * H_CH] = ow.z;
+                }
+            }
+        }
+
+        // ---- torque rows: this wavefront's items ----
+        const int cnt = items->count[wave];
+#pragma unroll 1
+        for (int it = 0; it < cnt; it++) {
+            const int code = items->code[wave][it];
+            const int pa = code & 7, pb = (code >> 3) & 7, k1 = (code >> 6) & 3, k2 = (code >> 8) & 3, out = code >> 10;
+            const double s0 = (k1 == 0) ? 1.0 : 0.0, s1 = (k1 == 1) ? 1.0 : 0.0, s2 = (k1 == 2) ? 1.0 : 0.0;
+            const double t0 = (k2 == 0) ? 1.0 : 0.0, t1 = (k2 == 1) ? 1.0 : 0.0, t2 = (k2 == 2) ? 1.0 : 0.0;
+            Kin<double> k0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
+                k0.al.c[k] = M->neg_gravity[k];
+            }
+#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
+#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
+            int l = 0;
+#pragma unroll 1
+            for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
+            Kin<HD> kh;
+            if (pa < pb) {
+                Kin<D1> k1s = promote<D1>(k0);
+                {   // l == pa: first seed
+                    const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                    hess_link(M, l, D1{cq, -sq * s0}, sg * D1{sq, cq * s0}, D1{HX(l, 0), s1}, D1{HX(l, 1), s2},
+                              lds[HL_MU + l * H_CH + lane], k1s);
+                    l++;
+                }
+#pragma unroll 1
+                for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1s);
+                kh = promote<HD>(k1s);
+            } else {
+                kh = promote<HD>(k0);
+            }
+            double phi_ab;
+            {   // l == pb: second seed (and the first one too when both sit on this joint)
+                const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                const double da = (pa == pb) ? s0 : 0.0, ea = (pa == pb) ? s1 : 0.0, fa = (pa == pb) ? s2 : 0.0;
+                hess_link(M, l, HD{cq, -sq * da, -sq * t0, -cq * da * t0}, sg * HD{sq, cq * da, cq * t0, -sq * da * t0},
+                          HD{HX(l, 0), ea, t1, 0.0}, HD{HX(l, 1), fa, t2, 0.0}, lds[HL_MU + l * H_CH + lane], kh);
+                phi_ab = hess_power_ab(M, l, kh);
+                l++;
+            }
+#pragma unroll 1
+            for (; l < NV; l++) {
+                hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh);
+                phi_ab += hess_power_ab(M, l, kh);
+            }
+#undef HX
+#undef HSG
+            if (live) phi[(long long)out * N + i0 + lane] = phi_ab;
+        }
+        __syncthreads();  // world-frame tables complete
+
+        // ---- obstacle rows: a wavefront per sphere, lane = sample; the four partial sums meet in LDS ----
+        {
+            double acc[H_PAIRS];
+#pragma unroll
+            for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
+            if (O > 0) {
+#pragma unroll 1
+                for (int sp = wave; sp < ns; sp += H_WAVES) {
+                    const double wgt = live ? lam[L.off_obs + (i0 + lane) * ns + sp] : 0.0;
+                    hess_sphere_terms(lds, lane, S, boxes, O, sp, wgt, acc);
+                }
+            }
+            double* part = lds + HL_ACC + wave * H_PAIRS * H_CH;
+#pragma unroll
+            for (int k = 0; k < H_PAIRS; k++) part[k * H_CH + lane] = acc[k];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H_PAIRS * H_CH; idx += RAPTOR_BLOCK) {
+            const int s = idx & (H_CH - 1), k = idx >> 6;
+            if (i0 + s < N) {
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < H_WAVES; w++) v += lds[HL_ACC + w * H_PAIRS * H_CH + idx];
+                phi[(long long)(HB_OBS + k) * N + i0 + s] = v;
+            }
+        }
+        __syncthreads();  // the sample tables are rewritten by the next pass
+    }
+}
+
+// H[b][c1 <= c2] from the per-sample blocks and the column weights (PiecewiseBezierCurves layout: W[i][order][c]).
+__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                                                                             const double* __restrict__ Phi, double* __restrict__ Hout) {
+    const long long b = blockIdx.x;
+    const int N = T->N, V = T->varLength, NV = T->Nact;
+    const double* phi = Phi + b * (long long)HB_NI * N;
+    double* H = Hout + b * ((long long)V * (V + 1) / 2);
+    for (int c1 = 0; c1 < V; c1++) {
+        const int j1 = c1 % NV;
+        const long long base = (long long)c1 * V - (long long)c1 * (c1 - 1) / 2;
+        for (int c2 = c1 + threadIdx.x; c2 < V; c2 += RAPTOR_BLOCK) {
+            const int j2 = c2 % NV;
+            const int lo = j1 < j2 ? j1 : j2, hi = j1 < j2 ? j2 : j1;
+            const int sym = pair_index(lo, hi);
+            const double* Pqq = phi + (long long)(HB_QQ + sym) * N;
+            const double* Pob = phi + (long long)(HB_OBS + sym) * N;
+            const double* Pvv = phi + (long long)(HB_VV + sym) * N;
+            const double* Pqv12 = phi + (long long)(HB_QV + j1 * NV + j2) * N;
+            const double* Pqv21 = phi + (long long)(HB_QV + j2 * NV + j1) * N;
+            const double* Pqa12 = phi + (long long)(HB_QA + j1 * NV + j2) * N;
+            const double* Pqa21 = phi + (long long)(HB_QA + j2 * NV + j1) * N;
+            double s = 0.0;
+            for (int i = 0; i < N; i++) {
+                const double* W = basis + (size_t)(i * 3) * V;
+                const double a0 = W[c1], a1 = W[V + c1], a2 = W[2 * V + c1];
+                const double b0 = W[c2], b1 = W[V + c2], b2 = W[2 * V + c2];
+                if ((a0 == 0.0 && a1 == 0.0 && a2 == 0.0) || (b0 == 0.0 && b1 == 0.0 && b2 == 0.0)) continue;  // another piece
+                s += a0 * b0 * (Pqq[i] + Pob[i]) + a1 * b1 * Pvv[i] + a0 * b1 * Pqv12[i] + a1 * b0 * Pqv21[i] + a0 * b2 * Pqa12[i] +
+                     a2 * b0 * Pqa21[i];
+            }
+            H[base + (c2 - c1)] = s;
+        }
+    }
+}
+
+#endif

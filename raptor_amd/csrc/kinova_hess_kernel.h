@@ -188,6 +188,65 @@ RD double wave_sum(double x) {
     return x;
 }
 
+// One sphere of one sample (lane): arg-min box, gradient n and Hessian K of the distance w.r.t. the centre, and the sphere's
+// contribution  wgt (J_a^T K J_b + n . H_ab)  to every pair a <= b < joint id, added into acc (upper triangle, row by row).
+// The joint id is wave-uniform (a wavefront owns one sphere): scalar branches.
+RD void hess_sphere_terms(const double* lds, const int lane, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes,
+          const int O, const int sp, const double wgt, double (&acc)[H_PAIRS]) {
+    constexpr int NV = 7;
+    const int jid = S->joint_id[sp];
+    const double* ro = lds + HL_RO + (S->ro_slot[jid - 1] * 12) * H_CH + lane;
+    M3 R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.m[k] = ro[k * H_CH];
+    const V3 point = v3(ro[9 * H_CH], ro[10 * H_CH], ro[11 * H_CH]) +
+                     mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+    BoxBest best;
+    best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
+    for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
+    V3 ng = v3(0, 0, 0);
+    double K0 = 0, K1 = 0, K2 = 0, K3 = 0, K4 = 0, K5 = 0;
+    if (best.d2 > 1e-12) {  // SQUARE_ROOT_THRESHOLD, BoxCollisionAvoidance.cpp:458
+        const DevBox* bx = boxes + best.idx;
+        M3 Rb;
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
+        const double inv = 1.0 / sqrt(best.d2);
+        const V3 nh = mul(Rb, best.dl) * inv;  // diff / |diff| in the world frame
+        const double ws = wgt * best.sign;
+        ng = nh * ws;
+        // P = sum over the clamped axes (dl != 0 exactly there: :233-250, :269-273) of r_k r_k^T
+        const double c0 = (best.dl.x != 0.0) ? 1.0 : 0.0, c1 = (best.dl.y != 0.0) ? 1.0 : 0.0, c2 = (best.dl.z != 0.0) ? 1.0 : 0.0;
+        const V3 r0 = col(Rb, 0), r1 = col(Rb, 1), r2 = col(Rb, 2);
+        const double kk = ws * inv;
+        K0 = kk * (c0 * r0.x * r0.x + c1 * r1.x * r1.x + c2 * r2.x * r2.x - nh.x * nh.x);
+        K1 = kk * (c0 * r0.x * r0.y + c1 * r1.x * r1.y + c2 * r2.x * r2.y - nh.x * nh.y);
+        K2 = kk * (c0 * r0.x * r0.z + c1 * r1.x * r1.z + c2 * r2.x * r2.z - nh.x * nh.z);
+        K3 = kk * (c0 * r0.y * r0.y + c1 * r1.y * r1.y + c2 * r2.y * r2.y - nh.y * nh.y);
+        K4 = kk * (c0 * r0.y * r0.z + c1 * r1.y * r1.z + c2 * r2.y * r2.z - nh.y * nh.z);
+        K5 = kk * (c0 * r0.z * r0.z + c1 * r1.z * r1.z + c2 * r2.z * r2.z - nh.z * nh.z);
+    }
+    // columns c < joint id move the sphere (jid is wave-uniform: scalar branches)
+    V3 om[NV], Jc[NV];
+#pragma unroll
+    for (int c = 0; c < NV; c++) {
+        if (c < jid) {
+            const double* wv = lds + HL_W + (c * 6) * H_CH + lane;
+            om[c] = v3(wv[0], wv[H_CH], wv[2 * H_CH]);
+            Jc[c] = cross(om[c], point - v3(wv[3 * H_CH], wv[4 * H_CH], wv[5 * H_CH]));
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NV; cb++) {
+        if (cb < jid) {
+            const V3 KJ = symmul(K0, K1, K2, K3, K4, K5, Jc[cb]);
+            const V3 nJ = cross(Jc[cb], ng);  // n . (w_a x J_b) = w_a . (J_b x n)
+#pragma unroll
+            for (int ca = 0; ca <= cb; ca++) acc[ca * 7 - (ca * (ca - 1)) / 2 + (cb - ca)] += dot(Jc[ca], KJ) + dot(om[ca], nJ);
+        }
+    }
+}
+
 // pairs dealt to the four wavefronts by cost (hyper-dual links (7 - b) dominate); entries = a * 8 + b
 __device__ const unsigned char H_PAIR_OF[H_WAVES][7] = {
     {0 * 8 + 0, 1 * 8 + 3, 1 * 8 + 4, 0 * 8 + 5, 1 * 8 + 5, 2 * 8 + 6, 3 * 8 + 6},
@@ -328,58 +387,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
             for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
 #pragma unroll 1
             for (int sp = SPLIT ? wave + H_WAVES * (int)blockIdx.y : wave; sp < ns; sp += SPLIT ? 7 * H_WAVES : H_WAVES) {
-                const int jid = S->joint_id[sp];
-                const double* ro = lds + HL_RO + (S->ro_slot[jid - 1] * 12) * H_CH + lane;
-                M3 R;
-#pragma unroll
-                for (int k = 0; k < 9; k++) R.m[k] = ro[k * H_CH];
-                const V3 point = v3(ro[9 * H_CH], ro[10 * H_CH], ro[11 * H_CH]) +
-                                 mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
-                BoxBest best;
-                best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
-                for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
                 const double wgt = live ? lam[L.off_obs + (i0 + lane) * ns + sp] * w0 * w0 : 0.0;
-                V3 ng = v3(0, 0, 0);
-                double K0 = 0, K1 = 0, K2 = 0, K3 = 0, K4 = 0, K5 = 0;
-                if (best.d2 > 1e-12) {  // SQUARE_ROOT_THRESHOLD, BoxCollisionAvoidance.cpp:458
-                    const DevBox* bx = boxes + best.idx;
-                    M3 Rb;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) Rb.m[k] = bx->R[k];
-                    const double inv = 1.0 / sqrt(best.d2);
-                    const V3 nh = mul(Rb, best.dl) * inv;  // diff / |diff| in the world frame
-                    const double ws = wgt * best.sign;
-                    ng = nh * ws;
-                    // P = sum over the clamped axes (dl != 0 exactly there: :233-250, :269-273) of r_k r_k^T
-                    const double c0 = (best.dl.x != 0.0) ? 1.0 : 0.0, c1 = (best.dl.y != 0.0) ? 1.0 : 0.0, c2 = (best.dl.z != 0.0) ? 1.0 : 0.0;
-                    const V3 r0 = col(Rb, 0), r1 = col(Rb, 1), r2 = col(Rb, 2);
-                    const double kk = ws * inv;
-                    K0 = kk * (c0 * r0.x * r0.x + c1 * r1.x * r1.x + c2 * r2.x * r2.x - nh.x * nh.x);
-                    K1 = kk * (c0 * r0.x * r0.y + c1 * r1.x * r1.y + c2 * r2.x * r2.y - nh.x * nh.y);
-                    K2 = kk * (c0 * r0.x * r0.z + c1 * r1.x * r1.z + c2 * r2.x * r2.z - nh.x * nh.z);
-                    K3 = kk * (c0 * r0.y * r0.y + c1 * r1.y * r1.y + c2 * r2.y * r2.y - nh.y * nh.y);
-                    K4 = kk * (c0 * r0.y * r0.z + c1 * r1.y * r1.z + c2 * r2.y * r2.z - nh.y * nh.z);
-                    K5 = kk * (c0 * r0.z * r0.z + c1 * r1.z * r1.z + c2 * r2.z * r2.z - nh.z * nh.z);
-                }
-                // columns c < joint id move the sphere (jid is wave-uniform: scalar branches)
-                V3 om[NV], Jc[NV];
-#pragma unroll
-                for (int c = 0; c < NV; c++) {
-                    if (c < jid) {
-                        const double* wv = lds + HL_W + (c * 6) * H_CH + lane;
-                        om[c] = v3(wv[0], wv[H_CH], wv[2 * H_CH]);
-                        Jc[c] = cross(om[c], point - v3(wv[3 * H_CH], wv[4 * H_CH], wv[5 * H_CH]));
-                    }
-                }
-#pragma unroll
-                for (int cb = 0; cb < NV; cb++) {
-                    if (cb < jid) {
-                        const V3 KJ = symmul(K0, K1, K2, K3, K4, K5, Jc[cb]);
-                        const V3 nJ = cross(Jc[cb], ng);  // n . (w_a x J_b) = w_a . (J_b x n)
-#pragma unroll
-                        for (int ca = 0; ca <= cb; ca++) acc[ca * 7 - (ca * (ca - 1)) / 2 + (cb - ca)] += dot(Jc[ca], KJ) + dot(om[ca], nJ);
-                    }
-                }
+                hess_sphere_terms(lds, lane, S, boxes, O, sp, wgt, acc);
             }
 #pragma unroll
             for (int k = 0; k < H_PAIRS; k++) {

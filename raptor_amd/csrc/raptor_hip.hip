@@ -3,6 +3,7 @@
 // every evaluation entry point runs on the GPU or returns RAPTOR_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include "period_kernel.h"
 #include "kinova_hess_kernel.h"
 #include "sphere_rows_kernel.h"
+#include "kinova_hess_blocks_kernel.h"
 #include "digit_constants.h"
 #include "digit_tables.h"
 
@@ -127,6 +129,9 @@ struct raptor_problem {
     DevBuf<DevSpheres> d_spheres;
     DevBuf<DevBox> d_boxes;
     DevBuf<double> s_hpart; // eval_h, split form: partial Hessians [32][7][28]
+    DevBuf<DevHessItems> d_hitems;  // eval_h over PiecewiseBezierCurves: the 154 block items dealt to four wavefronts
+    DevBuf<double> s_phi;           // ... and the per-sample blocks Phi[chunk][182][N]
+    std::vector<double> hbasis;     // host copy of the column-weight tables (PiecewiseBezierCurves): constant cost Hessians
     DevBuf<double> d_qdes;  // KinovaOptimizer::q_des, tplan_n (raptor_kinova_set_objective); tplan_n < 0: not set
     int tplan_n = -1;
     // staging for the *_host entry points (grown on demand, reused)
@@ -421,6 +426,60 @@ void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     hipLaunchKernelGGL((kinova_fused_kernel<DERIV>), dim3(grid), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_model.p,
                        p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
     HIP_CHECK(hipGetLastError());
+}
+
+// eval_h for the longer-horizon Kinova problem (kinova_hess_blocks_kernel.h)
+void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double* dLam, double* dH, hipStream_t st) {
+    if (!p.hmodel.serial_chain) throw unsupported_error("eval_h kernel: serial-chain models only");
+    for (int l = 0; l < p.hmodel.nv; l++)
+        if (std::abs(p.hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
+    if (!p.d_hitems.p) {  // deal the 154 block entries to the four wavefronts, longest first
+        struct Item { int j1, j2, k1, k2, out, cost; };
+        std::vector<Item> all;
+        auto add = [&](int ja, int ka, int jb, int kb, int out) {  // (ja, ka) and (jb, kb) in any order -> j1 <= j2
+            Item it = (ja <= jb) ? Item{ja, jb, ka, kb, out, 0} : Item{jb, ja, kb, ka, out, 0};
+            it.cost = (7 - it.j2) * 1000 + (it.j2 - it.j1) * 250 + it.j1 * 120 + 300;
+            all.push_back(it);
+        };
+        for (int a = 0; a < 7; a++)
+            for (int b = a; b < 7; b++) {
+                const int sym = a * 7 - (a * (a - 1)) / 2 + (b - a);
+                add(a, 0, b, 0, HB_QQ + sym);
+                add(a, 1, b, 1, HB_VV + sym);
+            }
+        for (int a = 0; a < 7; a++)
+            for (int b = 0; b < 7; b++) {
+                add(a, 0, b, 1, HB_QV + a * 7 + b);  // d2 / dq_a dv_b
+                add(a, 0, b, 2, HB_QA + a * 7 + b);  // d2 / dq_a da_b
+            }
+        std::sort(all.begin(), all.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+        DevHessItems h;
+        std::memset(&h, 0, sizeof(h));
+        long long load[H_WAVES] = {0, 0, 0, 0};
+        for (const Item& it : all) {
+            int w = 0;
+            for (int k = 1; k < H_WAVES; k++)
+                if (load[k] < load[w]) w = k;
+            if (h.count[w] >= HB_MAX_ITEMS) throw std::runtime_error("eval_h: item table overflow");
+            h.code[w][h.count[w]++] = it.j1 | (it.j2 << 3) | (it.k1 << 6) | (it.k2 << 8) | (it.out << 10);
+            load[w] += it.cost;
+        }
+        p.d_hitems.upload(&h, 1);
+    }
+    const int N = p.htraj.N, V = p.layout.n;
+    const size_t per_z = (size_t)HB_NI * N;
+    const int CH = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 26) / per_z));  // <= 512 MB of blocks in flight
+    p.s_phi.ensure((size_t)CH * per_z);
+    const size_t nh = (size_t)V * (V + 1) / 2;
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int nb = std::min(CH, B - b0);
+        hipLaunchKernelGGL(kinova_hess_blocks_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
+                           p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, p.d_hitems.p, dZ + (size_t)b0 * V,
+                           dLam + (size_t)b0 * p.layout.m, p.s_phi.p);
+        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_basis.p, p.s_phi.p,
+                           dH + (size_t)b0 * nh);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 // KinovaCustomizedConstraints rows for any trajectory whose columns move one joint each (sphere_rows_kernel.h)
@@ -737,6 +796,7 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     }
 
     upload_common(*p, basis, wsum);
+    if (p->kind == 3) p->hbasis = basis;
     p->d_spheres.upload(&S, 1);
     p->d_boxes.upload(boxes.data(), boxes.size());
     *out = p.release();
@@ -1492,6 +1552,30 @@ int raptor_eval_costs(raptor_problem* p, const double* d_Z, int B, int num_costs
     API_CATCH
 }
 
+int raptor_cost_hessian_host(raptor_problem* p, int kind, double* HESS) {
+    API_TRY
+    if (!p || !HESS) throw std::invalid_argument("null argument");
+    if (kind != RAPTOR_COST_MINIMIZE_PATH_LENGTH && kind != RAPTOR_COST_MINIMIZE_JERK)
+        throw unsupported_error("cost Hessian: built for MinimizePathLength / MinimizeJerk only");
+    if (p->htraj.type != RAPTOR_TRAJ_PIECEWISE_BEZIER) throw unsupported_error("cost Hessian: built for PiecewiseBezierCurves problems only");
+    // hess_f = (1/N) sum_i dP_i^T dP_i, dP_i = pq_pz(i+1) - pq_pz(i) (or pq_dd_pz): constant in z, a table like the basis (set-up)
+    const int N = p->htraj.N, V = p->htraj.varLength, Nact = p->htraj.Nact;
+    const int o = (kind == RAPTOR_COST_MINIMIZE_JERK) ? 2 : 0;
+    size_t it = 0;
+    for (int c1 = 0; c1 < V; c1++)
+        for (int c2 = c1; c2 < V; c2++, it++) {
+            double s = 0.0;
+            if (c1 % Nact == c2 % Nact)
+                for (int i = 0; i < N - 1; i++) {
+                    const double* W1 = &p->hbasis[(size_t)(i * 3 + o) * V];
+                    const double* W2 = &p->hbasis[(size_t)((i + 1) * 3 + o) * V];
+                    s += (W2[c1] - W1[c1]) * (W2[c2] - W1[c2]);
+                }
+            HESS[it] = s / N;
+        }
+    API_CATCH
+}
+
 int raptor_eval_costs_host(raptor_problem* p, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD) {
     API_TRY
     if (!p || !kinds || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
@@ -1553,7 +1637,12 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
     API_TRY
     if (!p || (B > 0 && (!d_Z || !d_lambda || !d_H))) throw std::invalid_argument("null argument");
     if (B < 0) throw std::invalid_argument("B < 0");
-    if (p->kind == 3) throw unsupported_error("eval_h: not built for PiecewiseBezierCurves (run Ipopt with hessian_approximation limited-memory)");
+    if (p->kind == 3) {  // KinovaLongerHorizonOptimizer: per-sample joint-space blocks, then the contraction with the column weights
+        if (d_obj_factor) throw std::invalid_argument("eval_h: this optimizer's objective is a weighted sum of Costs; add obj_factor * raptor_cost_hessian_host on the caller's side");
+        if (B == 0) return RAPTOR_OK;
+        hess_blocks_device(*p, d_Z, B, d_lambda, d_H, (hipStream_t)stream);
+        return RAPTOR_OK;
+    }
     if (p->kind != 1) throw std::runtime_error("eval_h: enable_hessian is false for this optimizer");  // Optimizer.cpp:513-515
     if (d_obj_factor && p->tplan_n < 0) throw std::invalid_argument("eval_h: raptor_kinova_set_objective has not been called");
     if (B == 0) return RAPTOR_OK;

@@ -370,9 +370,9 @@ class SingleStepOptimizer(Optimizer):
 
 class KinovaLongerHorizonOptimizer(SingleStepOptimizer):
     """KinovaLongerHorizonOptimizer::set_parameters (KinovaLongerHorizonOptimizer.cpp:18-122): PiecewiseBezierCurves, the four Kinova
-    blocks, MinimizePathLength (20) + MinimizeJerk (2).  The reference sets enable_hessian; exact Hessians are not built for this
-    trajectory class here, so the shell reports eval_h == False and a solver falls back to a quasi-Newton approximation
-    (Ipopt: hessian_approximation limited-memory)."""
+    blocks, MinimizePathLength (20) + MinimizeJerk (2), enable_hessian = true (:36).  eval_h = the library's constraint part plus
+    obj_factor * sum_k weight_k * hess_f_k (Optimizer::eval_hess_f, Optimizer.cpp:298-337; both costs are quadratic, their Hessians
+    constant)."""
 
     def __init__(self, api, model_handle, x0, T, N, degree, q0, qT, boxCenters, boxOrientation, boxSize,
                  joint_limits_buffer=None, velocity_limits_buffer=None, torque_limits_buffer=None,
@@ -386,3 +386,11 @@ class KinovaLongerHorizonOptimizer(SingleStepOptimizer):
         super().__init__(prob, x0, KinovaOptimizer.NAMES,
                          costs=((A.COST_MINIMIZE_PATH_LENGTH, 20.0, "minimize path length"),
                                 (A.COST_MINIMIZE_JERK, 2.0, "minimize jerk for smoothness")))
+        self.enable_hessian = True
+        self._hess_f_packed = sum(w * prob.cost_hessian_host(k) for k, w in zip(self.costsKinds, self.costsWeightVec_))
+
+    def eval_h(self, n, x, new_x, obj_factor, m, lam, new_lambda, values=True):
+        if not values or not self.enable_hessian:
+            return super().eval_h(n, x, new_x, obj_factor, m, lam, new_lambda, values)
+        H = super().eval_h(n, x, new_x, 0.0, m, lam, new_lambda, True)  # constraint part (Optimizer.cpp:565-619)
+        return H + obj_factor * self._hess_f_packed if obj_factor != 0 else H  # :552-563

@@ -719,8 +719,8 @@ def test_kinova_longer_horizon_rows(oracle, hip, kinova, fixed_ends, gripper, de
     Gh, Jh = ph.eval_host(Z[:1])
     check(Gh, Go)
     check(Jh, Jo)
-    with pytest.raises(A.RaptorError):
-        ph.eval_h_host(Z[:1], np.zeros((1, ph.m)))  # exact Hessians are not built for this trajectory class
+    with pytest.raises(A.RaptorInvalidArgument):
+        ph.eval_h_host(Z[:1], np.zeros((1, ph.m)), 1.0)  # this optimizer's objective is a sum of Costs: obj_factor stays with the caller
 
 
 def test_path_length_and_jerk_costs_gpu(oracle, hip, kinova):
@@ -772,3 +772,28 @@ def test_dual_kinova_arm_arm_rows_piecewise(oracle, hip, kinova):
     Gh, Jh = hip.dual_kinova_arm_arm_host(h1, h3, Z, N)
     check(Gh, Go)
     check(Jh, Jo)
+
+
+@pytest.mark.parametrize("fixed_ends,gripper,degree,N", [(True, False, 2, 6), (False, True, 3, 8), (True, True, 1, 70)])
+def test_kinova_longer_horizon_eval_h(oracle, hip, kinova_friction, fixed_ends, gripper, degree, N):
+    """Optimizer::eval_h for KinovaLongerHorizonOptimizer: per-sample joint-space blocks (unit-seeded hyper-dual recursion) contracted
+    with the PiecewiseBezierCurves column weights, against the oracle's literal tensors-and-products restatement."""
+    rng = np.random.default_rng(61 + degree)
+    q0, qT = (rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)) if fixed_ends else (None, None)
+    po, ph, keep = both(oracle, hip, lambda api, k: longer_horizon_problem(api, kinova_friction, k, degree, N, 3.0, q0, qT, gripper=gripper))
+    B = 3 if N < 20 else 1
+    Z = rng.uniform(-1, 1, (B, po.n))
+    lam = rng.uniform(-1, 1, (B, po.m))
+    Ho, Hh = po.eval_h_host(Z, lam), ph.eval_h_host(Z, lam)
+    assert Hh.shape == (B, po.n * (po.n + 1) // 2)
+    check(Hh, Ho)
+    off = po.block_offsets
+    for blk in range(4):
+        l2 = np.zeros_like(lam)
+        l2[:, off[blk]:off[blk + 1]] = lam[:, off[blk]:off[blk + 1]]
+        Hb = ph.eval_h_host(Z, l2)
+        check(Hb, po.eval_h_host(Z, l2))
+        if blk < 2:
+            assert np.all(Hb == 0.0)
+    for kind in (A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK):
+        check(ph.cost_hessian_host(kind), po.cost_hessian_host(kind), 1e-12)

@@ -159,7 +159,10 @@ def test_longer_horizon_shell(oracle, kinova):
     F, GR = opt.problem.costs_host(x, [A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK])
     assert opt.eval_f(n, x, True) == pytest.approx(20.0 * F[0, 0] + 2.0 * F[0, 1], rel=1e-14)
     assert np.allclose(opt.eval_grad_f(n, x, False), 20.0 * GR[0, 0] + 2.0 * GR[0, 1], rtol=1e-14, atol=0)
-    assert opt.eval_h(n, x, False, 1.0, m, np.zeros(m), True) is False
+    lam = np.random.default_rng(4).uniform(-1, 1, m)
+    want = opt.problem.eval_h_host(x, lam)[0] + 0.7 * (20.0 * opt.problem.cost_hessian_host(A.COST_MINIMIZE_PATH_LENGTH) +
+                                                        2.0 * opt.problem.cost_hessian_host(A.COST_MINIMIZE_JERK))
+    assert np.allclose(opt.eval_h(n, x, False, 0.7, m, lam, True), want, rtol=1e-14, atol=0)  # Optimizer.cpp:552-563 + 565-619
     f0 = opt.eval_f(n, x, True)
     res = opt.solve(max_iter=25)
     assert opt.ifFeasible and opt.obj_value_copy < f0
@@ -180,3 +183,5 @@ def test_longer_horizon_shell_on_the_gpu(oracle, hip, kinova):
     assert np.abs(oh.eval_grad_f(n, x, False) - oo.eval_grad_f(n, x, False)).max() < 1e-11
     assert H.rel_err(oh.eval_g(n, x, False, m), oo.eval_g(n, x, False, m)) < 1e-9
     assert H.rel_err(oh.eval_jac_g(n, x, False, m), oo.eval_jac_g(n, x, False, m)) < 1e-9
+    lam = np.random.default_rng(5).uniform(-1, 1, m)
+    assert H.rel_err(oh.eval_h(n, x, False, 0.5, m, lam, True), oo.eval_h(n, x, False, 0.5, m, lam, True)) < 1e-9
