@@ -283,6 +283,10 @@ def main() -> None:
             "lagrangian_hessians_per_s": B / (ms * 1e-3),
             "sample_evals_per_s": B * W.samples / (ms * 1e-3),
             "batch": B, "samples": W.samples,
+            # as the reference does it: second-order tensors + contraction + sphere Hessians ~ 1.2e5 flops / sample-eval
+            "roofline_fp64": {"bound": "fp64-valu", "achieved": B * W.samples * 1.2e5 / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": B * W.samples * 1.2e5 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                              "algorithmic_flops_per_sample_eval": 1.2e5},
         }
         if not args.no_latency:  # the Ipopt-driven use: one z per call, host-synchronised
             reps = 100
