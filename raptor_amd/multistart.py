@@ -68,3 +68,39 @@ def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: to
     out = out[:B]
     viol = out[:, 0]
     return viol, viol <= constr_viol_tol, (out[:, 1:] if gather_g else None)
+
+
+def select_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], cost: Callable[[torch.Tensor], torch.Tensor],
+                   Z_all: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor, constr_viol_tol: float = 1e-4, group=None) -> dict:
+    """The multi-start record of SURVEY.md 8e -- {cost f, worst violation, feasible} per problem -- and the winner: the feasible
+    problem of least cost, which is what the reference keeps across its random restarts (the Optimizer's own rule for iterates,
+    Optimization/src/Optimizer.cpp:187-193, applied across problems).  `cost`: Z_block -> f_block on this rank's device
+    (raptor_kinova_eval_objective / raptor_eval_costs weighted by the caller).  One all-gather of two doubles per problem.
+
+    Returns {"violation": [B], "feasible": [B] bool, "cost": [B], "best": index or -1}, identical on all ranks."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = Z_all.shape[0]
+    lo, hi = shard_range(B, world, rank)
+    per = -(-B // world) if world > 0 else B
+    Zb = Z_all[lo:hi].contiguous()
+    G = evaluate(Zb)
+    rec = torch.zeros((per, 2), dtype=torch.float64, device=G.device)
+    n = hi - lo
+    if n > 0:
+        rec[:n, 0] = violation(G, g_lb.to(G.device), g_ub.to(G.device))
+        rec[:n, 1] = cost(Zb).to(G.device).reshape(-1)
+    if world > 1:
+        out = torch.empty((world * per, 2), dtype=torch.float64, device=G.device)
+        dist.all_gather_into_tensor(out, rec, group=group)
+    else:
+        out = rec
+    out = out[:B]
+    feas = out[:, 0] <= constr_viol_tol
+    best = -1
+    if bool(feas.any()):
+        masked = torch.where(feas, out[:, 1], torch.full_like(out[:, 1], float("inf")))
+        best = int(torch.argmin(masked))  # first minimum: lowest problem index on a tie, on every rank alike
+    return {"violation": out[:, 0], "feasible": feas, "cost": out[:, 1], "best": best}

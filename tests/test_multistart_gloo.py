@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from raptor_amd import _capi as A  # noqa: E402
-from raptor_amd.multistart import evaluate_sharded, shard_range, violation  # noqa: E402
+from raptor_amd.multistart import evaluate_sharded, select_sharded, shard_range, violation  # noqa: E402
 from raptor_amd.urdf import load_urdf  # noqa: E402
 
 
@@ -56,7 +56,9 @@ def _worker(rank, world, port, B, out_dir):
         return torch.from_numpy(G)
 
     viol, feas, G = evaluate_sharded(evaluate, Z, lb, ub, gather_g=True)
-    torch.save({"viol": viol, "feas": feas, "G": G}, os.path.join(out_dir, f"r{rank}.pt"))
+    p.set_objective(np.full(7, 0.2), 2)
+    sel = select_sharded(evaluate, lambda Zb: torch.from_numpy(p.objective_host(Zb.numpy(), False)[0]), 0.05 * Z, lb, ub)
+    torch.save({"viol": viol, "feas": feas, "G": G, "sel": sel}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -79,7 +81,14 @@ def test_two_ranks_match_single_process(tmp_path, B):
     G, _ = p.eval_host(Z, A.EVAL_G)
     lb, ub = (torch.from_numpy(x) for x in p.bounds())
     want = violation(torch.from_numpy(G), lb, ub)
+    p.set_objective(np.full(7, 0.2), 2)
+    Gs, _ = p.eval_host(0.05 * Z, A.EVAL_G)
+    vs = violation(torch.from_numpy(Gs), lb, ub)
+    fs = torch.from_numpy(p.objective_host(0.05 * Z, False)[0])
+    ok = vs <= 1e-4
+    want_best = int(torch.argmin(torch.where(ok, fs, torch.full_like(fs, float("inf"))))) if bool(ok.any()) else -1
     for r in (r0, r1):
+        assert torch.equal(r["sel"]["cost"], fs) and torch.equal(r["sel"]["violation"], vs) and r["sel"]["best"] == want_best
         assert r["G"].shape == (B, p.m)
         assert torch.equal(r["G"], torch.from_numpy(G))
         assert torch.equal(r["viol"], want)
