@@ -178,7 +178,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
 }
 
 // H[b][c1 <= c2] from the per-sample blocks and the column weights (PiecewiseBezierCurves layout: W[i][order][c]).
+// `range[c]` = [first, last + 1) sample at which column c has a non-zero weight (a control point shapes two pieces only): two
+// columns interact over the intersection of their ranges, most pairs over none.
 __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                                                                             const int2* __restrict__ range,
                                                                              const double* __restrict__ Phi, double* __restrict__ Hout) {
     const long long b = blockIdx.x;
     const int N = T->N, V = T->varLength, NV = T->Nact;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(cons
     double* H = Hout + b * ((long long)V * (V + 1) / 2);
     for (int c1 = 0; c1 < V; c1++) {
         const int j1 = c1 % NV;
+        const int2 r1 = range[c1];
         const long long base = (long long)c1 * V - (long long)c1 * (c1 - 1) / 2;
         for (int c2 = c1 + threadIdx.x; c2 < V; c2 += RAPTOR_BLOCK) {
             const int j2 = c2 % NV;
@@ -199,11 +203,12 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(cons
             const double* Pqa12 = phi + (long long)(HB_QA + j1 * NV + j2) * N;
             const double* Pqa21 = phi + (long long)(HB_QA + j2 * NV + j1) * N;
             double s = 0.0;
-            for (int i = 0; i < N; i++) {
+            const int2 r2 = range[c2];
+            const int ilo = r1.x > r2.x ? r1.x : r2.x, ihi = r1.y < r2.y ? r1.y : r2.y;
+            for (int i = ilo; i < ihi; i++) {
                 const double* W = basis + (size_t)(i * 3) * V;
                 const double a0 = W[c1], a1 = W[V + c1], a2 = W[2 * V + c1];
                 const double b0 = W[c2], b1 = W[V + c2], b2 = W[2 * V + c2];
-                if ((a0 == 0.0 && a1 == 0.0 && a2 == 0.0) || (b0 == 0.0 && b1 == 0.0 && b2 == 0.0)) continue;  // another piece
                 s += a0 * b0 * (Pqq[i] + Pob[i]) + a1 * b1 * Pvv[i] + a0 * b1 * Pqv12[i] + a1 * b0 * Pqv21[i] + a0 * b2 * Pqa12[i] +
                      a2 * b0 * Pqa21[i];
             }

@@ -137,7 +137,13 @@ RD SV box_gradient_wrench(const DevBox* __restrict__ bx, const BoxBest& best, V3
     return SV{cross(point, dw), dw};
 }
 
-template <bool DERIV>
+// RECORD (the longer-horizon path, kinova_expand_kernel): instead of Jacobian rows the kernel leaves a per-sample-eval record in
+// `JAC` -- d tau / d(q, q_d, q_dd) as three 7 x 7 blocks and d dist / d q per sphere -- because PiecewiseBezierCurves columns
+// carry their own weight triples; the g rows are written as usual.
+#define KREC_D 0                                   // D[x][j][k] at x * 49 + j * 7 + k   (x = q, q_d, q_dd; row j, joint k)
+#define KREC_G 147                                 // gq[sphere][k]
+#define KREC_STRIDE (147 + 7 * RAPTOR_MAX_SPHERES) // 315 doubles
+template <bool DERIV, bool RECORD = false>
 __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes,
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     if (e < E) {
         const int i = (int)(e % N);
         const long long b = e / N;
-        const double* z = Z + b * NV;
+        const double* z = Z + b * L.n;  // L.n == 7 for ArmourBezierCurves
         const size_t rowbase = (size_t)b * L.m;
         const bool own = g < NV;  // lane 7 owns no joint
         const int gl = own ? g : NV - 1;
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         }
         double w0 = 0.0;
         if (DERIV) {
-            w0 = wsum[i * 3];
-            const double w1 = wsum[i * 3 + 1], w2 = wsum[i * 3 + 2];
+            w0 = RECORD ? 1.0 : wsum[i * 3];
+            const double w1 = RECORD ? 0.0 : wsum[i * 3 + 1], w2 = RECORD ? 0.0 : wsum[i * 3 + 2];
             const SV psi = crm(a, s) + crm(v, sd);
             const SV IS = applyO(I, s);
             const SV IdS = applyO(I, sd);
@@ -297,7 +303,33 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             wave_sync();
             // ---- phase E: lane g = column g of ptau_pz(i); the 7 lanes of a group write one 56-byte row per store, the
             // groups of a wave (consecutive samples) adjacent blocks of 392 bytes: no LDS staging for these rows ----
-            if (own) {
+            if (RECORD) {
+                if (own) {  // lane g = joint g: column g of the three blocks
+                    double* rec = JAC + (size_t)e * KREC_STRIDE + KREC_D + g;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        double dq, dv, da;
+                        if (j < g) {
+                            const SV sj = lds_sv(sl + KL_S + j * 6);
+                            dq = dot(sj, cq_);
+                            dv = dot(sj, cv);
+                            da = dot(sj, IS);
+                        } else {
+                            const SV ISj = lds_sv(sl + KL_X + 35 + j * 12), BtSj = lds_sv(sl + KL_X + 35 + j * 12 + 6);
+                            dq = dot(ISj, psi) + dot(BtSj, sd);
+                            dv = 2.0 * dot(ISj, sd) + dot(BtSj, s);
+                            da = dot(ISj, s);
+                            if (j == g) {
+                                da += M->armature[g];
+                                dv += M->damping[g];
+                            }
+                        }
+                        rec[j * NV] = dq;
+                        rec[49 + j * NV] = dv;
+                        rec[98 + j * NV] = da;
+                    }
+                }
+            } else if (own) {
                 double* trow = JAC + (rowbase + L.off_tau + (size_t)i * NV) * NV + g;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
@@ -374,6 +406,15 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
 
     if (!DERIV) return;
     __syncthreads();
+    if (RECORD) {  // sphere gradients per joint, staged in LDS by the sphere rounds -> the records
+        const int cnt = (int)(((e0 + K_EPB < E) ? e0 + K_EPB : E) - e0);
+        const int per = ns * NV;
+        for (int t = tid; t < cnt * per; t += RAPTOR_BLOCK) {
+            const int el = t / per, r = t - el * per;
+            JAC[(size_t)(e0 + el) * KREC_STRIDE + KREC_G + r] = lds[el * KL_STRIDE + KL_X + r];
+        }
+        return;
+    }
 
     // ---- copy-out: contiguous runs per constraint block, 16 bytes per lane ----
     const long long eend = (e0 + K_EPB < E) ? e0 + K_EPB : E;

@@ -131,6 +131,7 @@ struct raptor_problem {
     DevBuf<double> s_hpart; // eval_h, split form: partial Hessians [32][7][28]
     DevBuf<DevHessItems> d_hitems;  // eval_h over PiecewiseBezierCurves: the 154 block items dealt to four wavefronts
     DevBuf<double> s_phi;           // ... and the per-sample blocks Phi[chunk][182][N]
+    DevBuf<int2> d_colrange;        // ... and per column the sample range over which its weights are non-zero
     std::vector<double> hbasis;     // host copy of the column-weight tables (PiecewiseBezierCurves): constant cost Hessians
     DevBuf<double> d_qdes;  // KinovaOptimizer::q_des, tplan_n (raptor_kinova_set_objective); tplan_n < 0: not set
     int tplan_n = -1;
@@ -410,20 +411,20 @@ void launch_id(raptor_problem& p, const DevLayout& L, const double* dZ, int B, d
     HIP_CHECK(hipGetLastError());
 }
 
-template <bool DERIV>
+template <bool DERIV, bool RECORD = false>
 void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
     const size_t lds_bytes = (size_t)K_EPB * kinova_lds_stride(p.hspheres.num_spheres) * sizeof(double);
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[2] = {false, false};  // one flag pair per instantiation of this template
     if (!attr_set[DERIV]) {  // > 64 KiB of dynamic LDS needs the opt-in
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_fused_kernel<DERIV>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_fused_kernel<DERIV, RECORD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(K_EPB * kinova_lds_stride(RAPTOR_MAX_SPHERES) * sizeof(double))));
         attr_set[DERIV] = true;
     }
     const unsigned grid = (unsigned)((E + K_EPB - 1) / K_EPB);
-    hipLaunchKernelGGL((kinova_fused_kernel<DERIV>), dim3(grid), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_model.p,
+    hipLaunchKernelGGL((kinova_fused_kernel<DERIV, RECORD>), dim3(grid), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_model.p,
                        p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
     HIP_CHECK(hipGetLastError());
 }
@@ -467,6 +468,20 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
         p.d_hitems.upload(&h, 1);
     }
     const int N = p.htraj.N, V = p.layout.n;
+    if (!p.d_colrange.p) {
+        std::vector<int2> rg(V);
+        for (int c = 0; c < V; c++) {
+            int lo = N, hi = 0;
+            for (int i = 0; i < N; i++)
+                for (int o = 0; o < 3; o++)
+                    if (p.hbasis[(size_t)(i * 3 + o) * V + c] != 0.0) {
+                        lo = std::min(lo, i);
+                        hi = std::max(hi, i + 1);
+                    }
+            rg[c] = make_int2(lo, hi);
+        }
+        p.d_colrange.upload(rg.data(), rg.size());
+    }
     const size_t per_z = (size_t)HB_NI * N;
     const int CH = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 26) / per_z));  // <= 512 MB of blocks in flight
     p.s_phi.ensure((size_t)CH * per_z);
@@ -476,8 +491,8 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
         hipLaunchKernelGGL(kinova_hess_blocks_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
                            p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, p.d_hitems.p, dZ + (size_t)b0 * V,
                            dLam + (size_t)b0 * p.layout.m, p.s_phi.p);
-        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_basis.p, p.s_phi.p,
-                           dH + (size_t)b0 * nh);
+        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_basis.p, p.d_colrange.p,
+                           p.s_phi.p, dH + (size_t)b0 * nh);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -599,18 +614,34 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     if (p.kind == 1) {  // Kinova: one fused kernel
         if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
         else launch_kinova<false>(p, dZ, B, dG, nullptr, st);
-    } else if (p.kind == 3) {  // Kinova, longer horizon: limit rows per column, then the sphere rows
-        if (!p.hmodel.serial_chain) throw unsupported_error("inverse dynamics kernel: only serial-chain models are built so far");
-        if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
-        else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
-        launch_sphere_rows(p, dZ, B, dG, jac ? dJ : nullptr, st);
+    } else if (p.kind == 3) {  // Kinova, longer horizon: the fused kernel leaves records, a streaming kernel expands them
+        static const bool per_column = std::getenv("RAPTOR_LH_PER_COLUMN") != nullptr;  // the first, per-column form (A/B, tests)
+        if (per_column) {
+            if (!p.hmodel.serial_chain) throw unsupported_error("inverse dynamics kernel: only serial-chain models are built so far");
+            if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
+            else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
+            launch_sphere_rows(p, dZ, B, dG, jac ? dJ : nullptr, st);
+        } else if (!jac) {
+            launch_kinova<false>(p, dZ, B, dG, nullptr, st);
+        } else {
+            const long long E = (long long)B * p.htraj.N;
+            if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
+            p.s_core.ensure((size_t)E * KREC_STRIDE);
+            launch_kinova<true, true>(p, dZ, B, dG, p.s_core.p, st);
+            if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+            const size_t lds_bytes = (size_t)(KREC_STRIDE + 3 * p.layout.n) * sizeof(double);
+            if (lds_bytes > 64 * 1024) throw unsupported_error("Kinova expand kernel: too many decision variables");
+            hipLaunchKernelGGL(kinova_expand_kernel, dim3((unsigned)E), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_basis.p,
+                               p.layout, p.hspheres.num_spheres, p.s_core.p, dJ);
+            HIP_CHECK(hipGetLastError());
+        }
     } else if (p.kind == 2) {  // legged: core kernel, then the streaming expansion (timed separately)
         launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st, prof ? p.ev[p.ev_used + 1] : nullptr);
     } else {
         if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
         else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
     }
-    if (prof && p.kind != 2) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+    if (prof && p.kind != 2 && !(p.kind == 3 && jac)) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
     if (prof) {
         HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
         p.ev_used += 3;

@@ -105,6 +105,56 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void sphere_rows_kernel(
     }
 }
 
+// K_kinova_expand : pg_pz rows of the four Kinova blocks from the records of kinova_fused_kernel<true, RECORD> and the column
+// weights of the trajectory (PiecewiseBezierCurves: W[i][order][c], column c moves joint c mod 7):
+//     JointLimits row j:     [c mod 7 == j] W0[c]              VelocityLimits row j: [c mod 7 == j] W1[c]
+//     TorqueLimits row j:    Dq[j][c mod 7] W0[c] + Dv[j][c mod 7] W1[c] + Da[j][c mod 7] W2[c]     (InverseDynamics.cpp:137-139)
+//     obstacle row (sphere): gq[sphere][c mod 7] W0[c]                                                (KinovaCustomizedConstraints.cpp:112)
+// One workgroup per sample-eval: record + weights staged in LDS, the sample's four row pieces are contiguous in Optimizer
+// order and leave as 16-byte stores (V even) -- the HBM-bound half of the longer-horizon path, like legged_expand_kernel.
+__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_expand_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
+                                                                      const DevLayout L, const int ns, const double* __restrict__ REC,
+                                                                      double* __restrict__ JAC) {
+    extern __shared__ double le[];  // record (KREC_STRIDE), then W0 | W1 | W2 (3 V)
+    const int tid = threadIdx.x;
+    const long long e = blockIdx.x;
+    const int N = T->N, V = L.n;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    for (int t = tid; t < KREC_G + 7 * ns; t += RAPTOR_BLOCK) le[t] = REC[(size_t)e * KREC_STRIDE + t];
+    double* W = le + KREC_STRIDE;
+    for (int t = tid; t < 3 * V; t += RAPTOR_BLOCK) W[t] = basis[(size_t)(i * 3) * V + t];
+    __syncthreads();
+    const size_t rowbase = (size_t)b * L.m;
+    auto value = [&](int region, int r, int c) -> double {
+        const int jd = c % 7;
+        if (region == 0) return (jd == r) ? W[c] : 0.0;
+        if (region == 1) return (jd == r) ? W[V + c] : 0.0;
+        if (region == 2) return le[KREC_D + r * 7 + jd] * W[c] + le[KREC_D + 49 + r * 7 + jd] * W[V + c] + le[KREC_D + 98 + r * 7 + jd] * W[2 * V + c];
+        return le[KREC_G + r * 7 + jd] * W[c];
+    };
+#pragma unroll 1
+    for (int region = 0; region < 4; region++) {
+        const int rows = (region == 3) ? ns : 7;
+        const int off = (region == 0) ? L.off_q : (region == 1) ? L.off_qd : (region == 2) ? L.off_tau : L.off_obs;
+        double* dst = JAC + (rowbase + off + (size_t)i * rows) * V;
+        const int len = rows * V;
+        if ((V & 1) == 0 && (((size_t)dst) & 15) == 0) {
+            const int hv = V >> 1;
+            double2* dst2 = reinterpret_cast<double2*>(dst);
+            for (int t = tid; t < (len >> 1); t += RAPTOR_BLOCK) {
+                const int r = t / hv, c = 2 * (t - r * hv);
+                dst2[t] = make_double2(value(region, r, c), value(region, r, c + 1));
+            }
+        } else {
+            for (int t = tid; t < len; t += RAPTOR_BLOCK) {
+                const int r = t / V;
+                dst[t] = value(region, r, t - r * V);
+            }
+        }
+    }
+}
+
 // MinimizePathLength / MinimizeJerk (Costs/src/MinimizePathLength.cpp:10-61, MinimizeJerk.cpp:10-61) for any trajectory whose
 // columns move one joint each:  f = (1/N) sum_i 0.5 |x(i+1) - x(i)|^2,  x = q or q_dd;
 // grad_f(c) = (1/N) sum_i (x(i+1) - x(i))_{joint(c)} (w(i+1, c) - w(i, c)),  w = the column's pq_pz / pq_dd_pz entry.

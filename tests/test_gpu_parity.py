@@ -710,8 +710,8 @@ def test_kinova_longer_horizon_rows(oracle, hip, kinova, fixed_ends, gripper, de
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
-    Gh2, _ = ph.eval_host(Z, A.EVAL_G)  # eval_g alone
-    assert np.array_equal(Gh2, Gh)
+    Gh2, _ = ph.eval_host(Z, A.EVAL_G)  # eval_g alone: the values-only instantiation of the kernel (other instruction order)
+    check(Gh2, Gh, 1e-13)
     # ragged batch / no obstacles
     none = (np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)))
     po, ph, keep = both(oracle, hip, lambda api, k: longer_horizon_problem(api, kinova, k, degree, N, 3.0, q0, qT, boxes=none))
@@ -797,3 +797,18 @@ def test_kinova_longer_horizon_eval_h(oracle, hip, kinova_friction, fixed_ends, 
             assert np.all(Hb == 0.0)
     for kind in (A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK):
         check(ph.cost_hessian_host(kind), po.cost_hessian_host(kind), 1e-12)
+
+
+def test_kinova_longer_horizon_rows_per_column_form():
+    """The first form of the longer-horizon path (a forward-mode RNEA per column + sphere_rows_kernel) stays selectable with
+    RAPTOR_LH_PER_COLUMN=1; the switch is read once per process, so the same parity test runs in a child process."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RAPTOR_LH_PER_COLUMN="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "test_kinova_longer_horizon_rows and not per_column",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
