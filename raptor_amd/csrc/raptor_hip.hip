@@ -629,10 +629,14 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
             p.s_core.ensure((size_t)E * KREC_STRIDE);
             launch_kinova<true, true>(p, dZ, B, dG, p.s_core.p, st);
             if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
-            const size_t lds_bytes = (size_t)(KREC_STRIDE + 3 * p.layout.n) * sizeof(double);
-            if (lds_bytes > 64 * 1024) throw unsupported_error("Kinova expand kernel: too many decision variables");
-            hipLaunchKernelGGL(kinova_expand_kernel, dim3((unsigned)E), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_basis.p,
-                               p.layout, p.hspheres.num_spheres, p.s_core.p, dJ);
+            int spb = 4;  // samples per workgroup: longer contiguous pieces per store stream
+            if (const char* ev = getenv("RAPTOR_LH_SPB")) spb = std::max(1, std::min(8, atoi(ev)));
+            const size_t per_sample = (size_t)(KREC_STRIDE + 3 * p.layout.n) * sizeof(double);
+            while (spb > 1 && spb * per_sample > 64 * 1024) spb >>= 1;
+            if (spb * per_sample > 64 * 1024) throw unsupported_error("Kinova expand kernel: too many decision variables");
+            const long long groups = (p.htraj.N + spb - 1) / spb;
+            hipLaunchKernelGGL(kinova_expand_kernel, dim3((unsigned)(B * groups)), dim3(RAPTOR_BLOCK), spb * per_sample, st, p.d_traj.p,
+                               p.d_basis.p, p.layout, p.hspheres.num_spheres, spb, p.s_core.p, dJ);
             HIP_CHECK(hipGetLastError());
         }
     } else if (p.kind == 2) {  // legged: core kernel, then the streaming expansion (timed separately)

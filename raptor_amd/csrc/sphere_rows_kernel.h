@@ -110,46 +110,60 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void sphere_rows_kernel(
 //     JointLimits row j:     [c mod 7 == j] W0[c]              VelocityLimits row j: [c mod 7 == j] W1[c]
 //     TorqueLimits row j:    Dq[j][c mod 7] W0[c] + Dv[j][c mod 7] W1[c] + Da[j][c mod 7] W2[c]     (InverseDynamics.cpp:137-139)
 //     obstacle row (sphere): gq[sphere][c mod 7] W0[c]                                                (KinovaCustomizedConstraints.cpp:112)
-// One workgroup per sample-eval: record + weights staged in LDS, the sample's four row pieces are contiguous in Optimizer
-// order and leave as 16-byte stores (V even) -- the HBM-bound half of the longer-horizon path, like legged_expand_kernel.
+// One workgroup per `spb` consecutive samples of a decision vector: records + weights staged in LDS; each of the four row blocks
+// of those samples is ONE contiguous piece of the output in Optimizer order (spb * rows * V doubles -- the longer the piece, the
+// closer a streaming write gets to the HBM rate) and leaves as 16-byte stores (V even); no integer division in the
+// loops.  The HBM-bound half of the longer-horizon path, like legged_expand_kernel.
 __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_expand_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
-                                                                      const DevLayout L, const int ns, const double* __restrict__ REC,
-                                                                      double* __restrict__ JAC) {
-    extern __shared__ double le[];  // record (KREC_STRIDE), then W0 | W1 | W2 (3 V)
+                                                                      const DevLayout L, const int ns, const int spb,
+                                                                      const double* __restrict__ REC, double* __restrict__ JAC) {
+    extern __shared__ double le[];  // spb records (KREC_STRIDE each), then spb x (W0 | W1 | W2) (3 V each)
     const int tid = threadIdx.x;
-    const long long e = blockIdx.x;
     const int N = T->N, V = L.n;
-    const int i = (int)(e % N);
-    const long long b = e / N;
-    for (int t = tid; t < KREC_G + 7 * ns; t += RAPTOR_BLOCK) le[t] = REC[(size_t)e * KREC_STRIDE + t];
-    double* W = le + KREC_STRIDE;
-    for (int t = tid; t < 3 * V; t += RAPTOR_BLOCK) W[t] = basis[(size_t)(i * 3) * V + t];
+    const int groups = (N + spb - 1) / spb;
+    const long long b = blockIdx.x / groups;
+    const int i0 = (int)(blockIdx.x - b * groups) * spb;
+    const int cnt = min(spb, N - i0);
+    const int rlen = KREC_G + 7 * ns;
+    const size_t e0 = (size_t)b * N + i0;
+    for (int s = 0; s < cnt; s++)
+        for (int t = tid; t < rlen; t += RAPTOR_BLOCK) le[s * KREC_STRIDE + t] = REC[(e0 + s) * KREC_STRIDE + t];
+    double* Wall = le + spb * KREC_STRIDE;
+    for (int t = tid; t < cnt * 3 * V; t += RAPTOR_BLOCK) Wall[t] = basis[(size_t)(i0 * 3) * V + t];  // samples are adjacent in the table
     __syncthreads();
     const size_t rowbase = (size_t)b * L.m;
-    auto value = [&](int region, int r, int c) -> double {
-        const int jd = c % 7;
+    auto value = [&](int region, int s, int r, int c, int jd) -> double {
+        const double* W = Wall + s * 3 * V;
+        const double* rec = le + s * KREC_STRIDE;
         if (region == 0) return (jd == r) ? W[c] : 0.0;
         if (region == 1) return (jd == r) ? W[V + c] : 0.0;
-        if (region == 2) return le[KREC_D + r * 7 + jd] * W[c] + le[KREC_D + 49 + r * 7 + jd] * W[V + c] + le[KREC_D + 98 + r * 7 + jd] * W[2 * V + c];
-        return le[KREC_G + r * 7 + jd] * W[c];
+        if (region == 2) return rec[KREC_D + r * 7 + jd] * W[c] + rec[KREC_D + 49 + r * 7 + jd] * W[V + c] + rec[KREC_D + 98 + r * 7 + jd] * W[2 * V + c];
+        return rec[KREC_G + r * 7 + jd] * W[c];
     };
+    const bool wide = (V & 1) == 0 && (((size_t)JAC) & 15) == 0;
+    const int cw = wide ? 2 : 1;              // columns per store
+    const int per_row = V / cw;               // stores per row
+    const float inv_per_row = 1.0f / (float)per_row;
 #pragma unroll 1
     for (int region = 0; region < 4; region++) {
         const int rows = (region == 3) ? ns : 7;
         const int off = (region == 0) ? L.off_q : (region == 1) ? L.off_qd : (region == 2) ? L.off_tau : L.off_obs;
-        double* dst = JAC + (rowbase + off + (size_t)i * rows) * V;
-        const int len = rows * V;
-        if ((V & 1) == 0 && (((size_t)dst) & 15) == 0) {
-            const int hv = V >> 1;
-            double2* dst2 = reinterpret_cast<double2*>(dst);
-            for (int t = tid; t < (len >> 1); t += RAPTOR_BLOCK) {
-                const int r = t / hv, c = 2 * (t - r * hv);
-                dst2[t] = make_double2(value(region, r, c), value(region, r, c + 1));
-            }
-        } else {
-            for (int t = tid; t < len; t += RAPTOR_BLOCK) {
-                const int r = t / V;
-                dst[t] = value(region, r, t - r * V);
+        double* dst = JAC + (rowbase + off + (size_t)i0 * rows) * V;
+        const int len = cnt * rows * per_row;
+        const float inv_rows = 1.0f / (float)rows;
+        for (int t = tid; t < len; t += RAPTOR_BLOCK) {
+            // exact for these small integers: the quotient's distance to the next integer is >= 0.5 / divisor
+            const int ra = (int)(((float)t + 0.5f) * inv_per_row);  // row within the piece
+            const int c = (t - ra * per_row) * cw;
+            const int s = (int)(((float)ra + 0.5f) * inv_rows);
+            const int r = ra - s * rows;
+            const int q7 = (int)(((float)c + 0.5f) * (1.0f / 7.0f));
+            const int jd = c - 7 * q7;
+            if (wide) {
+                const int jd1 = (jd == 6) ? 0 : jd + 1;
+                reinterpret_cast<double2*>(dst)[t] = make_double2(value(region, s, r, c, jd), value(region, s, r, c + 1, jd1));
+            } else {
+                dst[t] = value(region, s, r, c, jd);
             }
         }
     }
