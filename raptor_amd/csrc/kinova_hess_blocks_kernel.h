@@ -178,41 +178,62 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
 }
 
 // H[b][c1 <= c2] from the per-sample blocks and the column weights (PiecewiseBezierCurves layout: W[i][order][c]).
-// `range[c]` = [first, last + 1) sample at which column c has a non-zero weight (a control point shapes two pieces only): two
-// columns interact over the intersection of their ranges, most pairs over none.
+// `pairs[p]` = (c1 | c2 << 16, first | end << 16): the p-th entry of the upper triangle (row by row) and the sample range over which
+// BOTH columns have a non-zero weight (a control point shapes two pieces only: most pairs interact over no sample at all).
+// One workgroup per z walks the samples in chunks of CH: the chunk of Phi ([182][CH + 1], padded against bank conflicts) and of W are
+// staged in LDS once, coalesced, then thread t owns the pairs p = t, t + 256, ... and adds the chunk's part of its sums -- one
+// running sum per pair in ascending sample order (carried through H between chunks by the same thread), so the result does not
+// depend on the chunking.  Phi is read from HBM exactly once.
 __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(const DevTraj* __restrict__ T, const double* __restrict__ basis,
-                                                                             const int2* __restrict__ range,
+                                                                             const int2* __restrict__ pairs, const int P, const int CH,
                                                                              const double* __restrict__ Phi, double* __restrict__ Hout) {
+    extern __shared__ double lc[];
+    const int tid = threadIdx.x;
     const long long b = blockIdx.x;
     const int N = T->N, V = T->varLength, NV = T->Nact;
+    const int PS = CH + 1;
+    double* lphi = lc;                   // [HB_NI][CH + 1]
+    double* lw = lc + HB_NI * PS;        // [CH][3][V]
     const double* phi = Phi + b * (long long)HB_NI * N;
-    double* H = Hout + b * ((long long)V * (V + 1) / 2);
-    for (int c1 = 0; c1 < V; c1++) {
-        const int j1 = c1 % NV;
-        const int2 r1 = range[c1];
-        const long long base = (long long)c1 * V - (long long)c1 * (c1 - 1) / 2;
-        for (int c2 = c1 + threadIdx.x; c2 < V; c2 += RAPTOR_BLOCK) {
-            const int j2 = c2 % NV;
-            const int lo = j1 < j2 ? j1 : j2, hi = j1 < j2 ? j2 : j1;
-            const int sym = pair_index(lo, hi);
-            const double* Pqq = phi + (long long)(HB_QQ + sym) * N;
-            const double* Pob = phi + (long long)(HB_OBS + sym) * N;
-            const double* Pvv = phi + (long long)(HB_VV + sym) * N;
-            const double* Pqv12 = phi + (long long)(HB_QV + j1 * NV + j2) * N;
-            const double* Pqv21 = phi + (long long)(HB_QV + j2 * NV + j1) * N;
-            const double* Pqa12 = phi + (long long)(HB_QA + j1 * NV + j2) * N;
-            const double* Pqa21 = phi + (long long)(HB_QA + j2 * NV + j1) * N;
-            double s = 0.0;
-            const int2 r2 = range[c2];
-            const int ilo = r1.x > r2.x ? r1.x : r2.x, ihi = r1.y < r2.y ? r1.y : r2.y;
-            for (int i = ilo; i < ihi; i++) {
-                const double* W = basis + (size_t)(i * 3) * V;
+    double* H = Hout + b * (long long)P;
+    const int sh = 31 - __clz(CH);       // CH is a power of two
+#pragma unroll 1
+    for (int i0 = 0; i0 < N; i0 += CH) {
+        const int cnt = min(CH, N - i0);
+        if (i0 > 0) __syncthreads();
+        for (int idx = tid; idx < HB_NI * CH; idx += RAPTOR_BLOCK) {
+            const int row = idx >> sh, s = idx & (CH - 1);
+            lphi[row * PS + s] = (s < cnt) ? phi[(long long)row * N + i0 + s] : 0.0;
+        }
+        for (int idx = tid; idx < cnt * 3 * V; idx += RAPTOR_BLOCK) lw[idx] = basis[(size_t)(i0 * 3) * V + idx];
+        __syncthreads();
+#pragma unroll 1
+        for (int p = tid; p < P; p += RAPTOR_BLOCK) {
+            const int2 pr = pairs[p];
+            const int c1 = pr.x & 0xffff, c2 = pr.x >> 16;
+            const int lo = max(pr.y & 0xffff, i0) - i0, hi = min(pr.y >> 16, i0 + cnt) - i0;
+            if (lo >= hi) {
+                if (i0 == 0) H[p] = 0.0;
+                continue;
+            }
+            const int j1 = c1 % NV, j2 = c2 % NV;
+            const int sym = pair_index(min(j1, j2), max(j1, j2));
+            const double* Pqq = lphi + (HB_QQ + sym) * PS;
+            const double* Pob = lphi + (HB_OBS + sym) * PS;
+            const double* Pvv = lphi + (HB_VV + sym) * PS;
+            const double* Pqv12 = lphi + (HB_QV + j1 * NV + j2) * PS;
+            const double* Pqv21 = lphi + (HB_QV + j2 * NV + j1) * PS;
+            const double* Pqa12 = lphi + (HB_QA + j1 * NV + j2) * PS;
+            const double* Pqa21 = lphi + (HB_QA + j2 * NV + j1) * PS;
+            double s = (i0 == 0) ? 0.0 : H[p];
+            for (int i = lo; i < hi; i++) {
+                const double* W = lw + i * 3 * V;
                 const double a0 = W[c1], a1 = W[V + c1], a2 = W[2 * V + c1];
                 const double b0 = W[c2], b1 = W[V + c2], b2 = W[2 * V + c2];
                 s += a0 * b0 * (Pqq[i] + Pob[i]) + a1 * b1 * Pvv[i] + a0 * b1 * Pqv12[i] + a1 * b0 * Pqv21[i] + a0 * b2 * Pqa12[i] +
                      a2 * b0 * Pqa21[i];
             }
-            H[base + (c2 - c1)] = s;
+            H[p] = s;
         }
     }
 }

@@ -131,7 +131,7 @@ struct raptor_problem {
     DevBuf<double> s_hpart; // eval_h, split form: partial Hessians [32][7][28]
     DevBuf<DevHessItems> d_hitems;  // eval_h over PiecewiseBezierCurves: the 154 block items dealt to four wavefronts
     DevBuf<double> s_phi;           // ... and the per-sample blocks Phi[chunk][182][N]
-    DevBuf<int2> d_colrange;        // ... and per column the sample range over which its weights are non-zero
+    DevBuf<int2> d_hpairs;          // ... and per (c1 <= c2) the columns and the sample range over which both weights are non-zero
     std::vector<double> hbasis;     // host copy of the column-weight tables (PiecewiseBezierCurves): constant cost Hessians
     DevBuf<double> d_qdes;  // KinovaOptimizer::q_des, tplan_n (raptor_kinova_set_objective); tplan_n < 0: not set
     int tplan_n = -1;
@@ -468,7 +468,7 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
         p.d_hitems.upload(&h, 1);
     }
     const int N = p.htraj.N, V = p.layout.n;
-    if (!p.d_colrange.p) {
+    if (!p.d_hpairs.p) {
         std::vector<int2> rg(V);
         for (int c = 0; c < V; c++) {
             int lo = N, hi = 0;
@@ -480,19 +480,34 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
                     }
             rg[c] = make_int2(lo, hi);
         }
-        p.d_colrange.upload(rg.data(), rg.size());
+        if (V > 0xffff || N > 0x7fff) throw unsupported_error("eval_h: problem too large for the pair table");
+        std::vector<int2> pr;
+        pr.reserve((size_t)V * (V + 1) / 2);
+        for (int c1 = 0; c1 < V; c1++)
+            for (int c2 = c1; c2 < V; c2++) {
+                const int lo = std::max(rg[c1].x, rg[c2].x), hi = std::max(lo, std::min(rg[c1].y, rg[c2].y));
+                pr.push_back(make_int2(c1 | (c2 << 16), lo | (hi << 16)));
+            }
+        p.d_hpairs.upload(pr.data(), pr.size());
     }
     const size_t per_z = (size_t)HB_NI * N;
     const int CH = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 26) / per_z));  // <= 512 MB of blocks in flight
     p.s_phi.ensure((size_t)CH * per_z);
     const size_t nh = (size_t)V * (V + 1) / 2;
+    int SCH = 8;  // samples per LDS chunk of the contraction (power of two)
+    if (const char* ev = getenv("RAPTOR_LH_HCH")) SCH = std::max(1, std::min(64, atoi(ev)));
+    while (SCH & (SCH - 1)) SCH &= SCH - 1;
+    auto lds_of = [&](int ch) { return ((size_t)HB_NI * (ch + 1) + (size_t)ch * 3 * V) * sizeof(double); };
+    while (SCH > 1 && lds_of(SCH) > 64 * 1024) SCH >>= 1;
+    if (lds_of(SCH) > 64 * 1024) throw unsupported_error("eval_h: too many decision variables");
+    const size_t lds_bytes = lds_of(SCH);
     for (int b0 = 0; b0 < B; b0 += CH) {
         const int nb = std::min(CH, B - b0);
         hipLaunchKernelGGL(kinova_hess_blocks_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
                            p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, p.d_hitems.p, dZ + (size_t)b0 * V,
                            dLam + (size_t)b0 * p.layout.m, p.s_phi.p);
-        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_traj.p, p.d_basis.p, p.d_colrange.p,
-                           p.s_phi.p, dH + (size_t)b0 * nh);
+        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_basis.p,
+                           p.d_hpairs.p, (int)nh, SCH, p.s_phi.p, dH + (size_t)b0 * nh);
         HIP_CHECK(hipGetLastError());
     }
 }
