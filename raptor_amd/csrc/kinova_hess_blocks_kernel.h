@@ -25,6 +25,7 @@
 #define HB_OBS 154
 #define HB_NI 182
 #define HB_MAX_ITEMS 48  // per wavefront (154 items dealt to four)
+#define HB_SPLIT 12      // workgroups per (z, pass) in the small-batch form: 11 share the items, one owns the obstacle entries
 
 // item code: j1 | j2 << 3 | k1 << 6 | k2 << 8 | out << 10   (j1 <= j2 joints, k = 0: q, 1: q_d, 2: q_dd seed, out = Phi row)
 struct DevHessItems {
@@ -49,9 +50,13 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
     const double* z = Z + b * (long long)L.n;
     const double* lam = lambda + b * (long long)L.m;
     double* phi = Phi + b * (long long)HB_NI * N;
+    // small batches are spread over more workgroups (launch grid y, z): blockIdx.y picks the item table, the LAST y also owns the
+    // obstacle entries; blockIdx.z strides the 64-sample passes.  Every Phi entry has one writer and one fixed summation order.
+    const DevHessItems* my = items + blockIdx.y;
+    const bool do_obs = blockIdx.y == gridDim.y - 1;
 
 #pragma unroll 1
-    for (int i0 = 0; i0 < N; i0 += H_CH) {
+    for (int i0 = blockIdx.z * H_CH; i0 < N; i0 += gridDim.z * H_CH) {
         for (int idx = tid; idx < H_CH * NV; idx += RAPTOR_BLOCK) {
             const int s = idx & (H_CH - 1), j = idx >> 6;
             const int i = min(i0 + s, N - 1);
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
         __syncthreads();
         const bool live = (i0 + lane) < N;
 
-        if (wave == 0 && O > 0) {  // world-frame joint axes / origins and sphere-link poses, lane = sample
+        if (wave == 0 && O > 0 && do_obs) {  // world-frame joint axes / origins and sphere-link poses, lane = sample
             M3 Rw;
 #pragma unroll
             for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -94,10 +99,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
         }
 
         // ---- torque rows: this wavefront's items ----
-        const int cnt = items->count[wave];
+        const int cnt = my->count[wave];
 #pragma unroll 1
         for (int it = 0; it < cnt; it++) {
-            const int code = items->code[wave][it];
+            const int code = my->code[wave][it];
             const int pa = code & 7, pb = (code >> 3) & 7, k1 = (code >> 6) & 3, k2 = (code >> 8) & 3, out = code >> 10;
             const double s0 = (k1 == 0) ? 1.0 : 0.0, s1 = (k1 == 1) ? 1.0 : 0.0, s2 = (k1 == 2) ? 1.0 : 0.0;
             const double t0 = (k2 == 0) ? 1.0 : 0.0, t1 = (k2 == 1) ? 1.0 : 0.0, t2 = (k2 == 2) ? 1.0 : 0.0;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
             double acc[H_PAIRS];
 #pragma unroll
             for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
-            if (O > 0) {
+            if (O > 0 && do_obs) {
 #pragma unroll 1
                 for (int sp = wave; sp < ns; sp += H_WAVES) {
                     const double wgt = live ? lam[L.off_obs + (i0 + lane) * ns + sp] : 0.0;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
         __syncthreads();
         for (int idx = tid; idx < H_PAIRS * H_CH; idx += RAPTOR_BLOCK) {
             const int s = idx & (H_CH - 1), k = idx >> 6;
-            if (i0 + s < N) {
+            if (do_obs && i0 + s < N) {
                 double v = 0.0;
 #pragma unroll
                 for (int w = 0; w < H_WAVES; w++) v += lds[HL_ACC + w * H_PAIRS * H_CH + idx];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_contract_kernel(cons
         for (int idx = tid; idx < cnt * 3 * V; idx += RAPTOR_BLOCK) lw[idx] = basis[(size_t)(i0 * 3) * V + idx];
         __syncthreads();
 #pragma unroll 1
-        for (int p = tid; p < P; p += RAPTOR_BLOCK) {
+        for (int p = blockIdx.y * RAPTOR_BLOCK + tid; p < P; p += gridDim.y * RAPTOR_BLOCK) {  // grid y > 1: small batches
             const int2 pr = pairs[p];
             const int c1 = pr.x & 0xffff, c2 = pr.x >> 16;
             const int lo = max(pr.y & 0xffff, i0) - i0, hi = min(pr.y >> 16, i0 + cnt) - i0;

@@ -454,18 +454,26 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
                 add(a, 0, b, 2, HB_QA + a * 7 + b);  // d2 / dq_a da_b
             }
         std::sort(all.begin(), all.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
-        DevHessItems h;
-        std::memset(&h, 0, sizeof(h));
-        long long load[H_WAVES] = {0, 0, 0, 0};
-        for (const Item& it : all) {
-            int w = 0;
-            for (int k = 1; k < H_WAVES; k++)
-                if (load[k] < load[w]) w = k;
-            if (h.count[w] >= HB_MAX_ITEMS) throw std::runtime_error("eval_h: item table overflow");
-            h.code[w][h.count[w]++] = it.j1 | (it.j2 << 3) | (it.k1 << 6) | (it.k2 << 8) | (it.out << 10);
-            load[w] += it.cost;
-        }
-        p.d_hitems.upload(&h, 1);
+        // table 0: the whole item set on one workgroup's four wavefronts (batched form); tables 1 .. HB_SPLIT: the item set over
+        // HB_SPLIT - 1 workgroups, the last table empty (that workgroup owns the obstacle entries) -- small batches
+        std::vector<DevHessItems> h(1 + HB_SPLIT);
+        std::memset(h.data(), 0, h.size() * sizeof(DevHessItems));
+        auto deal = [&](DevHessItems* tab, int ntab) {
+            std::vector<long long> load((size_t)ntab * H_WAVES, 0);
+            for (const Item& it : all) {
+                size_t w = 0;
+                for (size_t k = 1; k < load.size(); k++)
+                    if (load[k] < load[w]) w = k;
+                DevHessItems& t = tab[w / H_WAVES];
+                const int wv = (int)(w % H_WAVES);
+                if (t.count[wv] >= HB_MAX_ITEMS) throw std::runtime_error("eval_h: item table overflow");
+                t.code[wv][t.count[wv]++] = it.j1 | (it.j2 << 3) | (it.k1 << 6) | (it.k2 << 8) | (it.out << 10);
+                load[w] += it.cost;
+            }
+        };
+        deal(h.data(), 1);
+        deal(h.data() + 1, HB_SPLIT - 1);
+        p.d_hitems.upload(h.data(), h.size());
     }
     const int N = p.htraj.N, V = p.layout.n;
     if (!p.d_hpairs.p) {
@@ -503,10 +511,13 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
     const size_t lds_bytes = lds_of(SCH);
     for (int b0 = 0; b0 < B; b0 += CH) {
         const int nb = std::min(CH, B - b0);
-        hipLaunchKernelGGL(kinova_hess_blocks_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p,
-                           p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, p.d_hitems.p, dZ + (size_t)b0 * V,
-                           dLam + (size_t)b0 * p.layout.m, p.s_phi.p);
-        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_basis.p,
+        const int passes = (N + H_CH - 1) / H_CH;
+        const bool split = (long long)nb * passes <= 64;  // too few workgroups to fill the chip: spread items and passes
+        hipLaunchKernelGGL(kinova_hess_blocks_kernel, split ? dim3((unsigned)nb, HB_SPLIT, (unsigned)passes) : dim3((unsigned)nb),
+                           dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p,
+                           p.layout, p.d_hitems.p + (split ? 1 : 0), dZ + (size_t)b0 * V, dLam + (size_t)b0 * p.layout.m, p.s_phi.p);
+        const unsigned gy = split ? (unsigned)std::min<size_t>(16, (nh + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK) : 1u;
+        hipLaunchKernelGGL(kinova_hess_contract_kernel, dim3((unsigned)nb, gy), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_traj.p, p.d_basis.p,
                            p.d_hpairs.p, (int)nh, SCH, p.s_phi.p, dH + (size_t)b0 * nh);
         HIP_CHECK(hipGetLastError());
     }

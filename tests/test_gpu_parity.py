@@ -797,6 +797,10 @@ def test_kinova_longer_horizon_eval_h(oracle, hip, kinova_friction, fixed_ends, 
             assert np.all(Hb == 0.0)
     for kind in (A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK):
         check(ph.cost_hessian_host(kind), po.cost_hessian_host(kind), 1e-12)
+    # the batched launch form (one workgroup per z; the calls above spread a small batch over more workgroups): same bits per z
+    reps = 70
+    Hbig = ph.eval_h_host(np.tile(Z, (reps, 1)), np.tile(lam, (reps, 1)))
+    assert np.array_equal(Hbig[:B], Hh) and np.array_equal(Hbig[-B:], Hh)
 
 
 def test_kinova_longer_horizon_rows_per_column_form():
