@@ -104,6 +104,25 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
         for (int it = 0; it < cnt; it++) {
             const int code = my->code[wave][it];
             const int pa = code & 7, pb = (code >> 3) & 7, k1 = (code >> 6) & 3, k2 = (code >> 8) & 3, out = code >> 10;
+#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
+#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
+            if ((k1 == 2) != (k2 == 2)) {  // a q seed and a q_dd seed: the reduced first-order pass (kinova_hess_kernel.h)
+                const int jq = (k1 == 0) ? pa : pb, ja = (k1 == 0) ? pb : pa;
+                KinB<D1> kq;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    kq.ba.c[k] = D1{0.0, 0.0}; kq.bl.c[k] = D1{0.0, 0.0}; kq.wa.c[k] = D1{0.0, 0.0}; kq.wl.c[k] = D1{0.0, 0.0};
+                }
+                double acc = 0.0;
+#pragma unroll 1
+                for (int l = 0; l < NV; l++) {
+                    const double cq = HX(l, 2), sq = HX(l, 3), sd = (l == jq) ? 1.0 : 0.0;
+                    qa_link(M, l, D1{cq, -sq * sd}, HSG(l) * D1{sq, cq * sd}, (l == ja) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
+                    if (l >= pb) acc += qa_power_a(M, l, kq);
+                }
+                if (live) phi[(long long)out * N + i0 + lane] = acc;
+                continue;
+            }
             const double s0 = (k1 == 0) ? 1.0 : 0.0, s1 = (k1 == 1) ? 1.0 : 0.0, s2 = (k1 == 2) ? 1.0 : 0.0;
             const double t0 = (k2 == 0) ? 1.0 : 0.0, t1 = (k2 == 1) ? 1.0 : 0.0, t2 = (k2 == 2) ? 1.0 : 0.0;
             Kin<double> k0;
@@ -112,8 +131,6 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
                 k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
                 k0.al.c[k] = M->neg_gravity[k];
             }
-#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
-#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
             int l = 0;
 #pragma unroll 1
             for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);

@@ -182,6 +182,52 @@ RD double hess_power_ab(const DevModel* __restrict__ M, int l, const Kin<HD>& k)
     return s + dot_ab(k.wa, fa);
 }
 
+// ---- d2 phi / dq_a d(q_dd)_b: tau is linear in q_dd with the coefficient M(q), so  d phi / d(q_dd)_b = mu^T M(q) e_b = the virtual
+// power of the inertial forces I_l b_l, b = the acceleration field of a unit q_dd at joint b alone (no velocities, no gravity).
+// One first-order dual pass (seed q_a) over four motion vectors instead of a hyper-dual pass over six.
+template <class S>
+struct KinB {
+    T3<S> ba, bl, wa, wl;
+};
+template <int K, class S, class Tq>
+RD void qa_joint(Tq C, Tq Sn, double sg, double bseed, double mu, KinB<S>& k) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#define HROT(x) { const S xi_ = C * x.c[I] + Sn * x.c[J]; const S xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
+    HROT(k.ba) HROT(k.bl) HROT(k.wa) HROT(k.wl)
+#undef HROT
+    add_value(k.ba.c[K], sg * bseed);
+    add_value(k.wa.c[K], sg * mu);
+}
+template <class S, class Tq>
+RD void qa_link(const DevModel* __restrict__ M, int l, Tq C, Tq Sn, double bseed, double mu, KinB<S>& k) {
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+    k.bl = mulT(M->plR[l], k.bl + cross(k.ba, p));
+    k.ba = mulT(M->plR[l], k.ba);
+    k.wl = mulT(M->plR[l], k.wl + cross(k.wa, p));
+    k.wa = mulT(M->plR[l], k.wa);
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    if (aj == 3) qa_joint<2>(C, Sn, sg, bseed, mu, k);
+    else if (aj == 2) qa_joint<1>(C, Sn, sg, bseed, mu, k);
+    else qa_joint<0>(C, Sn, sg, bseed, mu, k);
+}
+RD double dot_a(const T3<D1>& x, const T3<D1>& y) {  // the dual part of x . y
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s += x.c[k].v * y.c[k].a + x.c[k].a * y.c[k].v;
+    return s;
+}
+RD double qa_power_a(const DevModel* __restrict__ M, int l, const KinB<D1>& k) {  // dual part of w . (I b)
+    const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
+    const double mass = M->mass[l];
+    T3<D1> gl = k.bl + cross(k.ba, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) gl.c[i] = mass * gl.c[i];
+    const T3<D1> fa = symmul(M->Ic[l], k.ba) + cross(c, gl);
+    return dot_a(k.wl, gl) + dot_a(k.wa, fa);
+}
+
 RD double wave_sum(double x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
