@@ -108,16 +108,29 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
 #define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
             if ((k1 == 2) != (k2 == 2)) {  // a q seed and a q_dd seed: the reduced first-order pass (kinova_hess_kernel.h)
                 const int jq = (k1 == 0) ? pa : pb, ja = (k1 == 0) ? pb : pa;
+                KinB<double> k0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { k0.ba.c[k] = 0.0; k0.bl.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0; }
+                int l = 0;
+#pragma unroll 1
+                for (; l < jq; l++)  // plain values up to the q seed
+                    qa_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), (l == ja) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], k0);
                 KinB<D1> kq;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    kq.ba.c[k] = D1{0.0, 0.0}; kq.bl.c[k] = D1{0.0, 0.0}; kq.wa.c[k] = D1{0.0, 0.0}; kq.wl.c[k] = D1{0.0, 0.0};
+                    kq.ba.c[k] = D1{k0.ba.c[k], 0.0}; kq.bl.c[k] = D1{k0.bl.c[k], 0.0};
+                    kq.wa.c[k] = D1{k0.wa.c[k], 0.0}; kq.wl.c[k] = D1{k0.wl.c[k], 0.0};
                 }
                 double acc = 0.0;
+                {   // l == jq: the seeded rotation
+                    const double cq = HX(l, 2), sq = HX(l, 3);
+                    qa_link(M, l, D1{cq, -sq}, HSG(l) * D1{sq, cq}, (l == ja) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
+                    if (l >= pb) acc += qa_power_a(M, l, kq);
+                    l++;
+                }
 #pragma unroll 1
-                for (int l = 0; l < NV; l++) {
-                    const double cq = HX(l, 2), sq = HX(l, 3), sd = (l == jq) ? 1.0 : 0.0;
-                    qa_link(M, l, D1{cq, -sq * sd}, HSG(l) * D1{sq, cq * sd}, (l == ja) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
+                for (; l < NV; l++) {
+                    qa_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), (l == ja) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
                     if (l >= pb) acc += qa_power_a(M, l, kq);
                 }
                 if (live) phi[(long long)out * N + i0 + lane] = acc;
