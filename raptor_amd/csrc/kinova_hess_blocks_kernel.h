@@ -106,6 +106,22 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
             const int pa = code & 7, pb = (code >> 3) & 7, k1 = (code >> 6) & 3, k2 = (code >> 8) & 3, out = code >> 10;
 #define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
 #define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
+            if (k1 == 1 && k2 == 1) {  // two q_d seeds: the bilinear pass in plain doubles (kinova_hess_kernel.h)
+                KinV kv;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    kv.xa.c[k] = 0.0; kv.xl.c[k] = 0.0; kv.ya.c[k] = 0.0; kv.yl.c[k] = 0.0;
+                    kv.ca.c[k] = 0.0; kv.cl.c[k] = 0.0; kv.wa.c[k] = 0.0; kv.wl.c[k] = 0.0;
+                }
+                double acc = 0.0;
+#pragma unroll 1
+                for (int l = 0; l < NV; l++) {
+                    vv_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), (l == pa) ? 1.0 : 0.0, (l == pb) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kv);
+                    if (l >= pb) acc += vv_power(M, l, kv);
+                }
+                if (live) phi[(long long)out * N + i0 + lane] = acc;
+                continue;
+            }
             if ((k1 == 2) != (k2 == 2)) {  // a q seed and a q_dd seed: the reduced first-order pass (kinova_hess_kernel.h)
                 const int jq = (k1 == 0) ? pa : pb, ja = (k1 == 0) ? pb : pa;
                 KinB<double> k0;

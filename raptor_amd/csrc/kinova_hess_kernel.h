@@ -228,6 +228,53 @@ RD double qa_power_a(const DevModel* __restrict__ M, int l, const KinB<D1>& k) {
     return dot_a(k.wl, gl) + dot_a(k.wa, fa);
 }
 
+// ---- d2 phi / d(q_d)_a d(q_d)_b: tau is quadratic in q_d, so the entry is the symmetric bilinear part of RNEA under the two
+// unit velocity fields (alpha: unit q_d at joint a, beta: at joint b) -- plain doubles, nothing to differentiate:
+//   c_l = Xup c_parent + crm(v_alpha) S [l == b] + crm(v_beta) S [l == a]          (the q_d q_d part of :157)
+//   f_l = I c_l + v_alpha x* I v_beta + v_beta x* I v_alpha                         (:244-246)
+struct KinV {
+    T3<double> xa, xl, ya, yl, ca, cl, wa, wl;  // alpha field, beta field, mixed acceleration, virtual velocity
+};
+template <int K>
+RD void vv_joint(double C, double Sn, double sa, double sb, double smu, KinV& k) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#define HROT(x) { const double xi_ = C * x.c[I] + Sn * x.c[J]; const double xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
+    HROT(k.xa) HROT(k.xl) HROT(k.ya) HROT(k.yl) HROT(k.ca) HROT(k.cl) HROT(k.wa) HROT(k.wl)
+#undef HROT
+    k.xa.c[K] += sa;
+    k.ya.c[K] += sb;
+    k.ca.c[I] += k.xa.c[J] * sb + k.ya.c[J] * sa;
+    k.ca.c[J] -= k.xa.c[I] * sb + k.ya.c[I] * sa;
+    k.cl.c[I] += k.xl.c[J] * sb + k.yl.c[J] * sa;
+    k.cl.c[J] -= k.xl.c[I] * sb + k.yl.c[I] * sa;
+    k.wa.c[K] += smu;
+}
+RD void vv_link(const DevModel* __restrict__ M, int l, double C, double Sn, double ua, double ub, double mu, KinV& k) {
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+#define HXT(a, lin) lin = mulT(M->plR[l], lin + cross(a, p)); a = mulT(M->plR[l], a);
+    HXT(k.xa, k.xl) HXT(k.ya, k.yl) HXT(k.ca, k.cl) HXT(k.wa, k.wl)
+#undef HXT
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    if (aj == 3) vv_joint<2>(C, Sn, sg * ua, sg * ub, sg * mu, k);
+    else if (aj == 2) vv_joint<1>(C, Sn, sg * ua, sg * ub, sg * mu, k);
+    else vv_joint<0>(C, Sn, sg * ua, sg * ub, sg * mu, k);
+}
+RD double dot3(const T3<double>& x, const T3<double>& y) { return x.c[0] * y.c[0] + x.c[1] * y.c[1] + x.c[2] * y.c[2]; }
+RD double vv_power(const DevModel* __restrict__ M, int l, const KinV& k) {
+    const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
+    const double mass = M->mass[l];
+    T3<double> hx = k.xl + cross(k.xa, c), hy = k.yl + cross(k.ya, c), gl = k.cl + cross(k.ca, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { hx.c[i] *= mass; hy.c[i] *= mass; gl.c[i] *= mass; }
+    const T3<double> ax = symmul(M->Ic[l], k.xa) + cross(c, hx);  // angular momentum of each field
+    const T3<double> ay = symmul(M->Ic[l], k.ya) + cross(c, hy);
+    const T3<double> fl = gl + cross(k.xa, hy) + cross(k.ya, hx);
+    const T3<double> fa = symmul(M->Ic[l], k.ca) + cross(c, gl) + cross(k.xa, ay) + cross(k.ya, ax) + cross(k.xl, hy) + cross(k.yl, hx);
+    return dot3(k.wl, fl) + dot3(k.wa, fa);
+}
+
 RD double wave_sum(double x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
