@@ -122,6 +122,40 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
                 if (live) phi[(long long)out * N + i0 + lane] = acc;
                 continue;
             }
+            if (k1 + k2 == 1) {  // a q seed and a q_d seed: the written-out q_d variation, first-order duals in q
+                const int jq = (k1 == 0) ? pa : pb, jb = (k1 == 0) ? pb : pa;
+                KinQ<double> k0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.da.c[k] = 0.0; k0.dl.c[k] = 0.0;
+                    k0.ea.c[k] = 0.0; k0.el.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
+                }
+                int l = 0;
+#pragma unroll 1
+                for (; l < jq; l++)
+                    qv_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), (l == jb) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], k0);
+                KinQ<D1> kq;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    kq.va.c[k] = D1{k0.va.c[k], 0.0}; kq.vl.c[k] = D1{k0.vl.c[k], 0.0}; kq.da.c[k] = D1{k0.da.c[k], 0.0};
+                    kq.dl.c[k] = D1{k0.dl.c[k], 0.0}; kq.ea.c[k] = D1{k0.ea.c[k], 0.0}; kq.el.c[k] = D1{k0.el.c[k], 0.0};
+                    kq.wa.c[k] = D1{k0.wa.c[k], 0.0}; kq.wl.c[k] = D1{k0.wl.c[k], 0.0};
+                }
+                double acc = 0.0;
+                {
+                    const double cq = HX(l, 2), sq = HX(l, 3);
+                    qv_link(M, l, D1{cq, -sq}, HSG(l) * D1{sq, cq}, HX(l, 0), (l == jb) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
+                    if (l >= pb) acc += qv_power_a(M, l, kq);
+                    l++;
+                }
+#pragma unroll 1
+                for (; l < NV; l++) {
+                    qv_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), (l == jb) ? 1.0 : 0.0, lds[HL_MU + l * H_CH + lane], kq);
+                    if (l >= pb) acc += qv_power_a(M, l, kq);
+                }
+                if (live) phi[(long long)out * N + i0 + lane] = acc;
+                continue;
+            }
             if ((k1 == 2) != (k2 == 2)) {  // a q seed and a q_dd seed: the reduced first-order pass (kinova_hess_kernel.h)
                 const int jq = (k1 == 0) ? pa : pb, ja = (k1 == 0) ? pb : pa;
                 KinB<double> k0;

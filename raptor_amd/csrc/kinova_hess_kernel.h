@@ -275,6 +275,53 @@ RD double vv_power(const DevModel* __restrict__ M, int l, const KinV& k) {
     return dot3(k.wl, fl) + dot3(k.wa, fa);
 }
 
+// ---- d2 phi / dq_a d(q_d)_b: the q_d-directional derivative of RNEA is written out (variation fields d = delta v, e = delta a
+// under a unit q_d at joint b; tau is quadratic in q_d), then differentiated once in q_a by first-order duals:
+//   e_l = Xup e_parent + crm(d_l) S q_d_l + crm(v_l) S [l == b],   delta f = I e + d x* I v + v x* I d
+template <class S>
+struct KinQ {
+    T3<S> va, vl, da, dl, ea, el, wa, wl;
+};
+template <int K, class S, class Tq>
+RD void qv_joint(Tq C, Tq Sn, double vj, double dvj, double smu, KinQ<S>& k) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#define HROT(x) { const S xi_ = C * x.c[I] + Sn * x.c[J]; const S xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
+    HROT(k.va) HROT(k.vl) HROT(k.da) HROT(k.dl) HROT(k.ea) HROT(k.el) HROT(k.wa) HROT(k.wl)
+#undef HROT
+    add_value(k.va.c[K], vj);
+    add_value(k.da.c[K], dvj);
+    k.ea.c[I] = k.ea.c[I] + k.da.c[J] * vj + k.va.c[J] * dvj;
+    k.ea.c[J] = k.ea.c[J] - (k.da.c[I] * vj + k.va.c[I] * dvj);
+    k.el.c[I] = k.el.c[I] + k.dl.c[J] * vj + k.vl.c[J] * dvj;
+    k.el.c[J] = k.el.c[J] - (k.dl.c[I] * vj + k.vl.c[I] * dvj);
+    add_value(k.wa.c[K], smu);
+}
+template <class S, class Tq>
+RD void qv_link(const DevModel* __restrict__ M, int l, Tq C, Tq Sn, double qd, double ub, double mu, KinQ<S>& k) {
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+#define HXT(a, lin) lin = mulT(M->plR[l], lin + cross(a, p)); a = mulT(M->plR[l], a);
+    HXT(k.va, k.vl) HXT(k.da, k.dl) HXT(k.ea, k.el) HXT(k.wa, k.wl)
+#undef HXT
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    if (aj == 3) qv_joint<2>(C, Sn, sg * qd, sg * ub, sg * mu, k);
+    else if (aj == 2) qv_joint<1>(C, Sn, sg * qd, sg * ub, sg * mu, k);
+    else qv_joint<0>(C, Sn, sg * qd, sg * ub, sg * mu, k);
+}
+RD double qv_power_a(const DevModel* __restrict__ M, int l, const KinQ<D1>& k) {  // dual part of w . delta f
+    const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
+    const double mass = M->mass[l];
+    T3<D1> hl = k.vl + cross(k.va, c), xl = k.dl + cross(k.da, c), gl = k.el + cross(k.ea, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { hl.c[i] = mass * hl.c[i]; xl.c[i] = mass * xl.c[i]; gl.c[i] = mass * gl.c[i]; }
+    const T3<D1> ha = symmul(M->Ic[l], k.va) + cross(c, hl);
+    const T3<D1> xa = symmul(M->Ic[l], k.da) + cross(c, xl);
+    const T3<D1> fl = gl + cross(k.da, hl) + cross(k.va, xl);
+    const T3<D1> fa = symmul(M->Ic[l], k.ea) + cross(c, gl) + cross(k.da, ha) + cross(k.va, xa) + cross(k.dl, hl) + cross(k.vl, xl);
+    return dot_a(k.wl, fl) + dot_a(k.wa, fa);
+}
+
 RD double wave_sum(double x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);

@@ -440,6 +440,7 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
         auto add = [&](int ja, int ka, int jb, int kb, int out) {  // (ja, ka) and (jb, kb) in any order -> j1 <= j2
             Item it = (ja <= jb) ? Item{ja, jb, ka, kb, out, 0} : Item{jb, ja, kb, ka, out, 0};
             it.cost = (7 - it.j2) * 1000 + (it.j2 - it.j1) * 250 + it.j1 * 120 + 300;
+            if (it.k1 + it.k2 == 1) it.cost = 300 + 7 * 200 + (7 - (it.k1 == 0 ? it.j1 : it.j2)) * 500 + (7 - it.j2) * 400;  // written-out q_d variation, D1 from the q seed on
             if (it.k1 == 1 && it.k2 == 1) it.cost = 300 + 7 * 200 + (7 - it.j2) * 200;  // bilinear pass in plain doubles
             if ((it.k1 == 2) != (it.k2 == 2)) it.cost = 300 + 100 * 7 + (7 - (it.k1 == 0 ? it.j1 : it.j2)) * 250 + (7 - it.j2) * 150;  // reduced pass: D1 from the q seed on  // reduced first-order pass over the whole chain
             all.push_back(it);
