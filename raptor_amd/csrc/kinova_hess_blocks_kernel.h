@@ -9,8 +9,8 @@
 //     H(c1, c2) = sum_i  w0 w0' (Pqq + Pobs)(j, j') + w1 w1' Pvv(j, j') + w0 w1' Pqv(j, j') + w1 w0' Pqv(j', j)
 //                      + w0 w2' Pqa(j, j') + w2 w0' Pqa(j', j),            j = c1 mod 7, j' = c2 mod 7
 // (tau is linear in q_dd and its q_dd coefficient does not depend on q_d: no vv-a, a-a blocks).
-//   kernel 1 (kinova_hess_blocks_kernel): the 154 block entries per sample by the hyper-dual forward recursion of
-//     kinova_hess_kernel.h with UNIT seeds -- an item is (joint j1 <= j2, kind of j1's seed, kind of j2's seed), a wavefront
+//   kernel 1 (kinova_hess_blocks_kernel): the 154 block entries per sample -- qq by the hyper-dual forward recursion of
+//     kinova_hess_kernel.h with UNIT seeds, vv / qa / qv by the reduced passes there (tau is quadratic in q_d, linear in q_dd) -- an item is (joint j1 <= j2, kind of j1's seed, kind of j2's seed), a wavefront
 //     owns an item, lanes = samples -- plus the 28 obstacle entries (a wavefront per sphere); Phi[b][182][N], sample-minor;
 //   kernel 2 (kinova_hess_contract_kernel): one workgroup per z, a thread per (c1 <= c2), fixed summation order over samples.
 #ifndef RAPTOR_KINOVA_HESS_BLOCKS_KERNEL_H
