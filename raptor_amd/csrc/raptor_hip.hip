@@ -515,7 +515,8 @@ void hess_blocks_device(raptor_problem& p, const double* dZ, int B, const double
     for (int b0 = 0; b0 < B; b0 += CH) {
         const int nb = std::min(CH, B - b0);
         const int passes = (N + H_CH - 1) / H_CH;
-        const bool split = (long long)nb * passes <= 64;  // too few workgroups to fill the chip: spread items and passes
+        static const long long split_max = getenv("RAPTOR_LH_SPLIT_MAX") ? atoll(getenv("RAPTOR_LH_SPLIT_MAX")) : 300;
+        const bool split = (long long)nb * passes <= split_max;  // too few workgroups to fill the chip: spread items and passes
         hipLaunchKernelGGL(kinova_hess_blocks_kernel, split ? dim3((unsigned)nb, HB_SPLIT, (unsigned)passes) : dim3((unsigned)nb),
                            dim3(RAPTOR_BLOCK), 0, st, p.d_model.p, p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p,
                            p.layout, p.d_hitems.p + (split ? 1 : 0), dZ + (size_t)b0 * V, dLam + (size_t)b0 * p.layout.m, p.s_phi.p);

@@ -798,7 +798,7 @@ def test_kinova_longer_horizon_eval_h(oracle, hip, kinova_friction, fixed_ends, 
     for kind in (A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK):
         check(ph.cost_hessian_host(kind), po.cost_hessian_host(kind), 1e-12)
     # the batched launch form (one workgroup per z; the calls above spread a small batch over more workgroups): same bits per z
-    reps = 70
+    reps = 350  # B * reps * passes > 300: the library switches to one workgroup per z
     Hbig = ph.eval_h_host(np.tile(Z, (reps, 1)), np.tile(lam, (reps, 1)))
     assert np.array_equal(Hbig[:B], Hh) and np.array_equal(Hbig[-B:], Hh)
 
