@@ -1716,8 +1716,9 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
         if (std::abs(p->hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
     const int tplan = p->tplan_n < 0 ? 0 : p->tplan_n;
     hipStream_t st = (hipStream_t)stream;
-    if (B <= 32) {  // few decision vectors (the Ipopt-driven case is B = 1): seven workgroups per z, then a fixed-order sum
-        p->s_hpart.ensure((size_t)32 * 7 * H_PAIRS);
+    static const int h_split_max = getenv("RAPTOR_H_SPLIT_MAX") ? atoi(getenv("RAPTOR_H_SPLIT_MAX")) : 112;  // measured crossover near B = 128
+    if (B <= h_split_max) {  // few decision vectors (the Ipopt-driven case is B = 1): seven workgroups per z, then a fixed-order sum
+        p->s_hpart.ensure((size_t)std::max(32, B) * 7 * H_PAIRS);
         hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
                            p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
                            p->s_hpart.p);

@@ -64,17 +64,17 @@ def test_eval_h_matches_oracle(oracle, hip, kinova, kinova_friction, gripper, fr
 
 
 def test_eval_h_both_launch_forms(oracle, hip, kinova):
-    """B <= 32 runs seven workgroups per z plus a fixed-order sum, larger batches one workgroup per z: same numbers, and a z
+    """B <= 112 runs seven workgroups per z plus a fixed-order sum, larger batches one workgroup per z: same numbers, and a z
     evaluated in either form gives bit-identical partial sums order-independently of its neighbours."""
     po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=70, boxes=H.reach_boxes()))  # two passes, ragged
     rng = np.random.default_rng(41)
-    B = 40
+    B = 120
     Z = rng.uniform(-1, 1, (B, 7))
     lam = rng.uniform(-1, 1, (B, po.m))
     po.set_objective(np.zeros(7), 3)
     ph.set_objective(np.zeros(7), 3)
     Hb = ph.eval_h_host(Z, lam, 1.0)            # batch form
-    check(Hb, po.eval_h_host(Z, lam, 1.0))
+    check(Hb[:24], po.eval_h_host(Z[:24], lam[:24], 1.0))
     Hs = ph.eval_h_host(Z[:7], lam[:7], 1.0)    # split form
     check(Hs, Hb[:7], 1e-12)
     assert np.array_equal(ph.eval_h_host(Z[3:4], lam[3:4], 1.0), Hs[3:4])  # deterministic, independent of the batch around it
