@@ -314,7 +314,7 @@ def main() -> None:
         ms = e0.elapsed_time(e1) / reps
         rec = {
             "kernel": "kinova_hessian_kernel (hyper-dual forward recursion, Lagrangian Hessian fused)" if armour else
-                      "kinova_hess_blocks_kernel (unit-seeded hyper-dual blocks) + kinova_hess_contract_kernel (column weights)",
+                      "kinova_hess_blocks_kernel (per-sample second-order blocks: hyper-dual qq, reduced vv / qv / qa passes) + kinova_hess_contract_kernel (column weights)",
             "ms_per_call": ms,
             "lagrangian_hessians_per_s": B / (ms * 1e-3),
             "sample_evals_per_s": B * W.samples / (ms * 1e-3),
