@@ -143,6 +143,14 @@ RD SV box_gradient_wrench(const DevBox* __restrict__ bx, const BoxBest& best, V3
 #define KREC_D 0                                   // D[x][j][k] at x * 49 + j * 7 + k   (x = q, q_d, q_dd; row j, joint k)
 #define KREC_G 147                                 // gq[sphere][k]
 #define KREC_STRIDE (147 + 7 * RAPTOR_MAX_SPHERES) // 315 doubles
+// Phase accounting: a build with -DKIN_STOP=k ends the kernel after phase k, storing a checksum of what is live
+// there so that the phase is not optimised away.  Measurement builds only (scripts/kinova_phases.sh); never defined in the product.
+#ifdef KIN_STOP
+#define KIN_PHASE_END(k, expr) if (KIN_STOP == (k)) { if (own && G != nullptr) G[rowbase + L.off_tau + (size_t)i * NV + g] = (expr); return; }
+#else
+#define KIN_PHASE_END(k, expr)
+#endif
+RD double sv_sum(SV x) { return x.a.x + x.a.y + x.a.z + x.l.x + x.l.y + x.l.z; }
 template <bool DERIV, bool RECORD = false>
 __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             }
         }
         wave_sync();
+        KIN_PHASE_END(1, q + qd + qdd + sq + cq)
 
         // ---- phase A: world-frame kinematics down to link gl (per-lane trip count) ----
         M3 Rw;
@@ -217,6 +226,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 ro[9] = ow.x; ro[10] = ow.y; ro[11] = ow.z;
             }
         }
+
+        KIN_PHASE_END(2, sv_sum(v) + sv_sum(a) + sv_sum(s) + sv_sum(sd) + Rw.m[0] + Rw.m[4] + Rw.m[8] + Rw.m[1] + Rw.m[5] + Rw.m[6] + ow.x + ow.y + ow.z)
 
         // ---- phase B: link g's inertia, momentum, wrench, Coriolis term (world frame, about the origin) ----
         InertiaO I;
@@ -270,6 +281,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             }
 #undef SCAN
         }
+
+        KIN_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sd) + sv_sum(v) + sv_sum(a))
 
         // ---- phase D: joint torque, and the per-joint 6-vectors of the analytic derivative ----
         if (own && G != nullptr) {
@@ -345,6 +358,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             }
         }
         wave_sync();  // the exchange area is reused for the sphere rows below
+        KIN_PHASE_END(4, w0 + sv_sum(s))
 
         // ---- spheres: KinovaCustomizedConstraints.cpp:88-157, BoxCollisionAvoidance.cpp:92-137, 290-373 ----
         // Whole rounds give one sphere to each of the 8 lanes.  A short last round (17 spheres: one left over) would leave
@@ -404,6 +418,9 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         }
     }
 
+#ifdef KIN_STOP
+    if (KIN_STOP == 5) return;
+#endif
     if (!DERIV) return;
     __syncthreads();
     if (RECORD) {  // sphere gradients per joint, staged in LDS by the sphere rounds -> the records

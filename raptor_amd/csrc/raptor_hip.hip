@@ -735,6 +735,7 @@ int raptor_id_problem_create(const raptor_model* model, const raptor_traj_desc* 
     p->block_offsets[1] = rows;
     p->g_lb.assign(rows, -1e19);
     p->g_ub.assign(rows, 1e19);
+    if (p->htraj.type == RAPTOR_TRAJ_PIECEWISE_BEZIER) p->hbasis = basis;  // raptor_cost_hessian_host reads the column weights
     upload_common(*p, basis, wsum);
     *out = p.release();
     API_CATCH
@@ -1625,6 +1626,7 @@ int raptor_cost_hessian_host(raptor_problem* p, int kind, double* HESS) {
     if (p->htraj.type != RAPTOR_TRAJ_PIECEWISE_BEZIER) throw unsupported_error("cost Hessian: built for PiecewiseBezierCurves problems only");
     // hess_f = (1/N) sum_i dP_i^T dP_i, dP_i = pq_pz(i+1) - pq_pz(i) (or pq_dd_pz): constant in z, a table like the basis (set-up)
     const int N = p->htraj.N, V = p->htraj.varLength, Nact = p->htraj.Nact;
+    if (p->hbasis.size() < (size_t)N * 3 * V) throw unsupported_error("cost Hessian: this problem keeps no host copy of the column weights");
     const int o = (kind == RAPTOR_COST_MINIMIZE_JERK) ? 2 : 0;
     size_t it = 0;
     for (int c1 = 0; c1 < V; c1++)

@@ -803,6 +803,24 @@ def test_kinova_longer_horizon_eval_h(oracle, hip, kinova_friction, fixed_ends, 
     assert np.array_equal(Hbig[:B], Hh) and np.array_equal(Hbig[-B:], Hh)
 
 
+def test_cost_hessian_on_inverse_dynamics_problem(oracle, hip, kinova):
+    """raptor_cost_hessian_host on a handle made by raptor_id_problem_create over PiecewiseBezierCurves (the handle
+    tests/test_oracle_pins.py builds): the host copy of the column weights must exist there too; other trajectory classes are
+    refused with an error code, never read out of bounds."""
+    rng = np.random.default_rng(3)
+    q0, qT = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    for kw in (dict(q0=q0, qT=qT), dict()):
+        po, ph, keep = both(oracle, hip, lambda api, k: H.id_problem(api, kinova, k, ttype=A.TRAJ_PIECEWISE_BEZIER, T=3.0, N=12,
+                                                                     degree=2, disc=A.TIME_UNIFORM, **kw))
+        for kind in (A.COST_MINIMIZE_PATH_LENGTH, A.COST_MINIMIZE_JERK):
+            Hh, Ho = ph.cost_hessian_host(kind), po.cost_hessian_host(kind)
+            assert np.abs(Ho).max() > 0
+            check(Hh, Ho, 1e-12)
+    pb = H.id_problem(hip, kinova, keep, ttype=A.TRAJ_BEZIER, degree=5)
+    with pytest.raises(A.RaptorError):
+        pb.cost_hessian_host(A.COST_MINIMIZE_JERK)
+
+
 def test_kinova_longer_horizon_rows_per_column_form():
     """The first form of the longer-horizon path (a forward-mode RNEA per column + sphere_rows_kernel) stays selectable with
     RAPTOR_LH_PER_COLUMN=1; the switch is read once per process, so the same parity test runs in a child process."""
