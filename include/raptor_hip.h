@@ -380,6 +380,20 @@ int raptor_eval_h_batch(raptor_problem* problem, const double* d_Z, int B, const
 int raptor_eval_h_batch_host(raptor_problem* problem, const double* Z, int B, const double* obj_factor, const double* lambda,
                              double* H);
 
+/*
+ * Allocation-free variant of raptor_eval_h_batch.  It has NO counterpart in the reference: it exists for callers that cannot
+ * allocate device memory while they call -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, same kernels and bit-identical results as raptor_eval_h_batch in its small-batch form; the partial-Hessian
+ * buffer that entry point allocates on demand is here a fixed workspace inside the library (172 KB per GPU, held until the
+ * process ends; its per-GPU address is looked up in raptor_init or on the first call on a device).
+ * Limits: KinovaOptimizer (ARMOUR_BEZIER) problems only; B <= RAPTOR_H_NOALLOC_MAX_B, larger batches return
+ * RAPTOR_ERR_INVALID_ARGUMENT.  All calls on one GPU share that workspace: calls that overlap in time on one GPU (different
+ * streams or threads) race on it; calls ordered on one stream do not.  Nothing in it has to be cleared between calls.
+ */
+#define RAPTOR_H_NOALLOC_MAX_B 112
+int raptor_eval_h_batch_noalloc(raptor_problem* problem, const double* d_Z, int B, const double* d_obj_factor,
+                                const double* d_lambda, double* d_H, void* hip_stream);
+
 /* Measurement aid with no counterpart in the reference: `blocks` workgroups each fill one contiguous chunk of
  * `chunk_doubles` doubles with 16-byte stores -- the write pattern of the Jacobian kernels, used by scripts/bw_probe.py
  * to calibrate the achievable HBM write rate next to the roofline numbers. */

@@ -230,7 +230,7 @@ EXPORTS = [
     "cost_hessian_host",
 ]
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
-DEVICE_ONLY_EXPORTS = ["probe_fill"]
+DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc"]
 
 
 class CApi:
@@ -281,6 +281,7 @@ class CApi:
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         if prefix == "raptor_":
             f("probe_fill").argtypes = [vp, C.c_longlong, C.c_longlong, vp]
+            f("eval_h_batch_noalloc").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
         self._f = f
 
     # -- helpers -------------------------------------------------------------------------
@@ -568,6 +569,10 @@ class ProblemHandle:
 
     def eval_h_device(self, d_Z: int, B: int, d_obj_factor: int, d_lambda: int, d_H: int, stream: int = 0) -> None:
         self.api.check(self.api.fn("eval_h_batch")(self.handle, d_Z, B, d_obj_factor or None, d_lambda, d_H, stream or None))
+
+    def eval_h_device_noalloc(self, d_Z: int, B: int, d_obj_factor: int, d_lambda: int, d_H: int, stream: int = 0) -> None:
+        """raptor_eval_h_batch_noalloc: the small-batch eval_h on the library's fixed workspace (no device allocation)."""
+        self.api.check(self.api.fn("eval_h_batch_noalloc")(self.handle, d_Z, B, d_obj_factor or None, d_lambda, d_H, stream or None))
 
     def inverse_dynamics_hessian_host(self, Z, N: int, nv: int):
         """Oracle only: InverseDynamics::ptau_pz_pz [B][N][nv][n][n]."""

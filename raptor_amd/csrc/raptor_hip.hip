@@ -684,6 +684,28 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
 
 }  // namespace
 
+// Fixed-size device workspace of raptor_eval_h_batch_noalloc (include/raptor_hip.h): the partial Hessians [B][7][28] of the
+// split-form eval_h kernels, B <= RAPTOR_H_NOALLOC_MAX_B.  172 KB, held by every GPU the library runs on until the process ends.
+// Host code needs the array's device address, which differs per GPU: it is looked up once per device with
+// hipGetSymbolAddress and cached here; kernels receive that address as an ordinary pointer argument.
+static __device__ __align__(256) double scratch[RAPTOR_H_NOALLOC_MAX_B * 7 * H_PAIRS];
+namespace {
+constexpr int kMaxDevices = 64;
+double* g_scratch_addr[kMaxDevices] = {nullptr};
+double* scratch_device_address() {
+    int dev = -1;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) throw std::runtime_error("device index out of range for the eval_h workspace table");
+    if (g_scratch_addr[dev] == nullptr) {
+        double* addr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress((void**)&addr, HIP_SYMBOL(scratch)));
+        if (addr == nullptr) throw hip_error("hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_addr[dev] = addr;
+    }
+    return g_scratch_addr[dev];
+}
+}  // namespace
+
 // bandwidth probe (scripts/bw_probe.py): every workgroup writes one contiguous chunk with 16-byte stores per lane
 __global__ __launch_bounds__(256) void probe_fill_kernel(double* __restrict__ p, const long long chunk) {
     double* dst = p + (long long)blockIdx.x * chunk;
@@ -705,6 +727,7 @@ int raptor_init(int device) {
     HIP_CHECK(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) throw std::invalid_argument("raptor_init: no such device");
     HIP_CHECK(hipSetDevice(device));
+    (void)scratch_device_address();  // set-up of the allocation-free eval_h entry point: this device's workspace address
     API_CATCH
 }
 
@@ -1732,6 +1755,33 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
                            p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
                            d_H);
     }
+    HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+// raptor_eval_h_batch restricted to its small-batch (split) form, with the library-owned partial-Hessian buffer replaced by the
+// fixed device workspace above: no hipMalloc / hipFree on this path.
+int raptor_eval_h_batch_noalloc(raptor_problem* p, const double* d_Z, int B, const double* d_obj_factor, const double* d_lambda,
+                                double* d_H, void* stream) {
+    API_TRY
+    if (!p || (B > 0 && (!d_Z || !d_lambda || !d_H))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B > RAPTOR_H_NOALLOC_MAX_B) throw std::invalid_argument("eval_h (allocation-free): B exceeds the workspace limit of 112 decision vectors");
+    if (p->kind != 1) throw std::runtime_error("eval_h (allocation-free): KinovaOptimizer (ArmourBezierCurves) problems only");
+    if (d_obj_factor && p->tplan_n < 0) throw std::invalid_argument("eval_h: raptor_kinova_set_objective has not been called");
+    if (B == 0) return RAPTOR_OK;
+    if (!p->hmodel.serial_chain) throw unsupported_error("eval_h kernel: serial-chain models only");
+    for (int l = 0; l < p->hmodel.nv; l++)
+        if (std::abs(p->hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
+    double* part = scratch_device_address();  // device address of the workspace on the current GPU (hipGetSymbolAddress, cached)
+    const int tplan = p->tplan_n < 0 ? 0 : p->tplan_n;
+    hipStream_t st = (hipStream_t)stream;
+    // every entry part[b][k][pair], b < B, has exactly one writer in the first kernel: nothing has to start at zero
+    hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                       p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, part, p->d_wsum.p,
+                       d_obj_factor, tplan, B, d_H);
     HIP_CHECK(hipGetLastError());
     API_CATCH
 }
