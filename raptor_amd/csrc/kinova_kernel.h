@@ -62,7 +62,53 @@ RD SV applyO(const InertiaO& I, SV x) {
 RD SV applyQ(const double* Q, V3 t, SV x) {
     return SV{symmul(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], x.a) + cross(t, x.l), cross(x.a, t)};
 }
-RD double shfl_down8(double x, int d) { return __shfl_down(x, d, KG); }
+// Cross-lane moves inside a 16-lane row by DPP (a VALU modifier: no LDS round trip, unlike ds_bpermute behind __shfl_*).
+// The 8-lane groups are half rows, so a shift by D < 8 never leaves the row for the lanes that use the value; lanes whose
+// source falls outside their own group must be masked by the caller.
+//   dpp_down<D>(x): lane l receives x of lane l + D   (row_shl:D)
+//   dpp_up<D>(x)  : lane l receives x of lane l - D   (row_shr:D)
+template <int CTRL>
+RD double dpp_mov64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int D> RD double dpp_down(double x) { return dpp_mov64<0x100 + D>(x); }
+template <int D> RD double dpp_up(double x) { return dpp_mov64<0x110 + D>(x); }
+template <int D> RD V3 dpp_up(V3 a) { return V3{dpp_up<D>(a.x), dpp_up<D>(a.y), dpp_up<D>(a.z)}; }
+template <int D> RD SV dpp_up(SV a) { return SV{dpp_up<D>(a.a), dpp_up<D>(a.l)}; }
+
+// rigid transform of a link frame (rotation R, origin p) and the composition parent * child
+struct XF {
+    M3 R;
+    V3 p;
+};
+RD XF compose(const XF& a, const XF& b) {
+    XF c;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) c.R.m[3 * i + j] = a.R.m[3 * i] * b.R.m[j] + a.R.m[3 * i + 1] * b.R.m[3 + j] + a.R.m[3 * i + 2] * b.R.m[6 + j];
+    c.p = a.p + mul(a.R, b.p);
+    return c;
+}
+template <int D> RD XF dpp_up(const XF& a) {
+    XF c;
+#pragma unroll
+    for (int k = 0; k < 9; k++) c.R.m[k] = dpp_up<D>(a.R.m[k]);
+    c.p = dpp_up<D>(a.p);
+    return c;
+}
+// one round of the inclusive prefix scans of phase A over the 8 lanes of a group (Hillis-Steele, distance D)
+template <int D> RD void scan_xf(XF& x, int g) {
+    const XF left = dpp_up<D>(x);
+    if (g >= D) x = compose(left, x);
+}
+template <int D> RD void scan_sv(SV& x, int g) {
+    const SV left = dpp_up<D>(x);
+    if (g >= D) x = x + left;
+}
 
 // ---- BoxCollisionAvoidance (Constraints/src/BoxCollisionAvoidance.cpp:92-137, 290-373) ----
 // Running arg-min over the boxes.  `key` = sign * |diff|^2 (0 below SQUARE_ROOT_THRESHOLD) orders candidates exactly as the
@@ -181,41 +227,55 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         double q, qd, qdd, sq, cq;
         traj_joint(T, basis, z, i, gl, q, qd, qdd);
         sincos(q, &sq, &cq);
-        if (own) {
-            double* x = sl + KL_X + g * 5;
-            x[0] = qd; x[1] = qdd; x[2] = cq; x[3] = sq; x[4] = q;
-            if (G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
-                G[rowbase + L.off_q + (size_t)i * NV + g] = q;
-                G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;
-            }
+        if (own && G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
+            G[rowbase + L.off_q + (size_t)i * NV + g] = q;
+            G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;
         }
-        wave_sync();
         KIN_PHASE_END(1, q + qd + qdd + sq + cq)
 
-        // ---- phase A: world-frame kinematics down to link gl (per-lane trip count) ----
-        M3 Rw;
+        // ---- phase A: world-frame kinematics of link g as prefix scans over the group's 8 lanes ----
+        // lane g forms its joint's transform in the parent link's frame, X_g = placement_g * Rot/Trans(q_g); an inclusive
+        // scan of rigid-transform products gives the world pose of every link in three rounds.  The joint axis is a column
+        // of that pose, v_g = sum_{k <= g} s_k qd_k and a_g = -a_grav + sum_{k <= g} (s_k qdd_k + (v_k x s_k) qd_k) are two
+        // more scans of 6-vectors ((v_{k-1} x s_k qd_k) = (v_k x s_k) qd_k because s_k x s_k = 0).
+        const int jt = M->jtype[gl];
+        const int aj = jt < 0 ? -jt : jt;
+        const double sg = jt < 0 ? -1.0 : 1.0;
+        XF X;
+        SV s;
+        {
+            M3 P;
 #pragma unroll
-        for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-        V3 ow = v3(0, 0, 0);
-        SV v = sv_zero(), vprev = sv_zero();
-        SV a = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
-        SV s = sv_zero();
-#pragma unroll 1
-        for (int l = 0; l <= gl; l++) {
-            const double* x = sl + KL_X + l * 5;
-            const double lqd = x[0], lqdd = x[1], lcq = x[2], lsq = x[3], lq = x[4];
-            const M3 A = mul(Rw, M->plR[l]);
-            V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
-            M3 R;
-            joint_world(M->jtype[l], lq, lcq, lsq, A, R, o, s);
-            const SV sqd = s * lqd;
-            vprev = v;
-            a = a + s * lqdd + crm(v, sqd);
-            v = v + sqd;
-            Rw = R;
-            ow = o;
+            for (int k = 0; k < 9; k++) P.m[k] = M->plR[gl][k];
+            V3 o = v3(M->plp[gl][0], M->plp[gl][1], M->plp[gl][2]);
+            joint_world(jt, q, cq, sq, P, X.R, o, s);  // the axis it returns is in the parent's frame: recomputed below
+            X.p = o;
+            if (!own) {  // lane 7 owns no joint: identity, so that it ends up with link 6's pose (and zero mass below)
+#pragma unroll
+                for (int k = 0; k < 9; k++) X.R.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+                X.p = v3(0, 0, 0);
+            }
         }
-        const SV sd = crm(vprev, s);  // = v x s
+        scan_xf<1>(X, g);
+        scan_xf<2>(X, g);
+        scan_xf<4>(X, g);
+        const M3 Rw = X.R;
+        const V3 ow = X.p;
+        {
+            // a rotation about local axis k leaves column k of the frame alone: the world axis is a column of the link's own pose
+            const V3 ax = col_sel(Rw, (aj <= 3 ? aj : aj - 3) - 1) * (own ? sg : 0.0);
+            s = (aj <= 3) ? SV{ax, cross(ow, ax)} : SV{v3(0, 0, 0), ax};
+        }
+        SV v = s * qd;
+        scan_sv<1>(v, g);
+        scan_sv<2>(v, g);
+        scan_sv<4>(v, g);
+        const SV sd = crm(v, s);  // = v x s
+        SV a = s * qdd + sd * qd;
+        scan_sv<1>(a, g);
+        scan_sv<2>(a, g);
+        scan_sv<4>(a, g);
+        a.l = a.l + v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2]);
         if (own) {
             lds_put(sl + KL_S + g * 6, s);
             const int slot = S->ro_slot[g];
@@ -266,21 +326,20 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             }
         }
 
-        // ---- phase C: composites = suffix sums over the chain (8-lane scan, lane 7 contributes zero) ----
+        // ---- phase C: composites = suffix sums over the chain (8-lane scan by DPP row shifts, lane 7 contributes zero) ----
         SV F = f, H = h;
-#pragma unroll
-        for (int d = 1; d < KG; d <<= 1) {
-            const bool take = (g + d) < KG;
-#define SCAN(x) { const double y_ = shfl_down8(x, d); if (take) x += y_; }
-            SCAN(F.a.x) SCAN(F.a.y) SCAN(F.a.z) SCAN(F.l.x) SCAN(F.l.y) SCAN(F.l.z)
-            if (DERIV) {
-                SCAN(H.a.x) SCAN(H.a.y) SCAN(H.a.z) SCAN(H.l.x) SCAN(H.l.y) SCAN(H.l.z)
-                SCAN(I.m) SCAN(I.hv.x) SCAN(I.hv.y) SCAN(I.hv.z)
-                SCAN(I.xx) SCAN(I.xy) SCAN(I.xz) SCAN(I.yy) SCAN(I.yz) SCAN(I.zz)
-                SCAN(Qt[0]) SCAN(Qt[1]) SCAN(Qt[2]) SCAN(Qt[3]) SCAN(Qt[4]) SCAN(Qt[5])
-            }
-#undef SCAN
+#define SCAN(x, D) { const double y_ = dpp_down<D>(x); if (g + D < KG) x += y_; }
+#define SCAN_ROUND(D)                                                                                   \
+        SCAN(F.a.x, D) SCAN(F.a.y, D) SCAN(F.a.z, D) SCAN(F.l.x, D) SCAN(F.l.y, D) SCAN(F.l.z, D)       \
+        if (DERIV) {                                                                                    \
+            SCAN(H.a.x, D) SCAN(H.a.y, D) SCAN(H.a.z, D) SCAN(H.l.x, D) SCAN(H.l.y, D) SCAN(H.l.z, D)   \
+            SCAN(I.m, D) SCAN(I.hv.x, D) SCAN(I.hv.y, D) SCAN(I.hv.z, D)                                \
+            SCAN(I.xx, D) SCAN(I.xy, D) SCAN(I.xz, D) SCAN(I.yy, D) SCAN(I.yz, D) SCAN(I.zz, D)         \
+            SCAN(Qt[0], D) SCAN(Qt[1], D) SCAN(Qt[2], D) SCAN(Qt[3], D) SCAN(Qt[4], D) SCAN(Qt[5], D)   \
         }
+        SCAN_ROUND(1) SCAN_ROUND(2) SCAN_ROUND(4)
+#undef SCAN_ROUND
+#undef SCAN
 
         KIN_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sd) + sv_sum(v) + sv_sum(a))
 

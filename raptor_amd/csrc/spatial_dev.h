@@ -50,6 +50,11 @@ RD M3 mul(const M3& A, const double* B) {  // A * B, B row-major 3x3 (uniform co
     return C;
 }
 RD V3 col(const M3& R, int j) { return V3{R.m[j], R.m[3 + j], R.m[6 + j]}; }
+// column j for a j that differs between lanes: selects, so that R stays in registers
+RD V3 col_sel(const M3& R, int j) {
+    return V3{j == 0 ? R.m[0] : (j == 1 ? R.m[1] : R.m[2]), j == 0 ? R.m[3] : (j == 1 ? R.m[4] : R.m[5]),
+              j == 0 ? R.m[6] : (j == 1 ? R.m[7] : R.m[8])};
+}
 
 // spatial motion vector [angular; linear] / force vector [moment; force], world frame at world origin
 struct SV {
@@ -134,7 +139,7 @@ RD void joint_world(int jt, double q, double cq, double sq, const M3& A, M3& R, 
         V3 ax = col(A, 2) * sg;
         s = SV{ax, cross(o, ax)};
     } else {  // prismatic along axis aj-4
-        V3 ax = col(A, aj - 4) * sg;
+        V3 ax = col_sel(A, aj - 4) * sg;
         o = axpy(o, q, ax);
         s = SV{V3{0, 0, 0}, ax};
     }
