@@ -48,11 +48,15 @@ struct DevSpheres {
     int ro_slot[RAPTOR_MAX_NV];        // link -> slot of its world pose in the kernel's LDS exchange area (-1: no sphere)
     double offset[RAPTOR_MAX_SPHERES][3];
     double radius[RAPTOR_MAX_SPHERES];
+    int slot[RAPTOR_MAX_SPHERES];      // = ro_slot[joint_id - 1]: one table look-up instead of two dependent ones in the kernel
 };
 
-// one oriented box: R (row-major), centre, half sizes stay as the reference keeps them (full size / 2.0)
+// one oriented box: R (row-major), centre, full edge lengths as the reference keeps them; cl = R^T centre and hs = size / 2.0
+// (exact) are what the distance loop of the fused Kinova kernel reads, laid out first so that they arrive in one run of scalar loads
 struct DevBox {
     double R[9];
+    double cl[3];
+    double hs[3];
     double center[3];
     double size[3];
 };

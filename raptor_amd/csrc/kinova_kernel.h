@@ -183,6 +183,70 @@ RD SV box_gradient_wrench(const DevBox* __restrict__ bx, const BoxBest& best, V3
     return SV{cross(point, dw), dw};
 }
 
+// ---- the same distance in the form the fused kernel's box loop uses ----
+// e_k = |lp_k| - hs_k per box axis (lp = R^T point - R^T centre).  Outside (some e_k > 0): |diff|^2 = sum max(e_k, 0)^2 -- the
+// reference's lp_k - clamp(lp_k) is exactly +-max(e_k, 0).  Inside: the nearest face is the first axis of largest e_k (the
+// reference's first-minimum scan over x-, x+, y-, y+, z-, z+ of hs_k -+ lp_k), |diff| = -e_k.  The loop orders boxes by the signed
+// square key = +-|diff|^2 (0 below SQUARE_ROOT_THRESHOLD), monotone in the reference's sign * sqrt(|diff|^2): strict `<` keeps
+// first-minimum-wins on ties, and only (key, index) live through the loop; the winner's direction is rebuilt once per sphere.
+RD void box_local(const double* __restrict__ R, const double* __restrict__ cl, const double* __restrict__ hs, V3 p, V3& lp, V3& e) {
+    lp.x = R[0] * p.x + (R[3] * p.y + (R[6] * p.z - cl[0]));
+    lp.y = R[1] * p.x + (R[4] * p.y + (R[7] * p.z - cl[1]));
+    lp.z = R[2] * p.x + (R[5] * p.y + (R[8] * p.z - cl[2]));
+    e = v3(fabs(lp.x) - hs[0], fabs(lp.y) - hs[1], fabs(lp.z) - hs[2]);
+}
+RD double box_key(const DevBox* __restrict__ bx, V3 p) {
+    V3 lp, e;
+    box_local(bx->R, bx->cl, bx->hs, p, lp, e);
+    const double emax = fmax(e.x, fmax(e.y, e.z));
+    const double mx = fmax(e.x, 0.0), my = fmax(e.y, 0.0), mz = fmax(e.z, 0.0);
+    const double d2o = mx * mx + (my * my + mz * mz), d2i = emax * emax;
+    const bool outside = emax > 0.0;
+    const double d2 = outside ? d2o : d2i;
+    const double key = outside ? d2o : -d2i;
+    return (d2 > 1e-12) ? key : 0.0;
+}
+struct BoxHit {
+    double dist;  // signed distance (BoxCollisionAvoidance.cpp:300-303)
+    V3 n;         // d dist / d point in world axes (zero below the threshold, :359-372)
+};
+RD BoxHit box_hit(const DevBox* __restrict__ bx, V3 p) {
+    double R[9], cl[3], hs[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = bx->R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cl[k] = bx->cl[k]; hs[k] = bx->hs[k]; }
+    V3 lp, e;
+    box_local(R, cl, hs, p, lp, e);
+    const double emax = fmax(e.x, fmax(e.y, e.z));
+    const bool outside = emax > 0.0;
+    const int kmax = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
+    const double mx = fmax(e.x, 0.0), my = fmax(e.y, 0.0), mz = fmax(e.z, 0.0);
+    V3 dl;  // point - closest point, box frame
+    dl.x = outside ? (lp.x > 0.0 ? mx : -mx) : (kmax == 0 ? (lp.x > 0.0 ? e.x : -e.x) : 0.0);
+    dl.y = outside ? (lp.y > 0.0 ? my : -my) : (kmax == 1 ? (lp.y > 0.0 ? e.y : -e.y) : 0.0);
+    dl.z = outside ? (lp.z > 0.0 ? mz : -mz) : (kmax == 2 ? (lp.z > 0.0 ? e.z : -e.z) : 0.0);
+    const double d2 = outside ? mx * mx + (my * my + mz * mz) : emax * emax;
+    BoxHit h;
+    h.dist = 0.0;
+    h.n = v3(0, 0, 0);
+    if (d2 > 1e-12) {
+        const double r = sqrt(d2), sgn = outside ? 1.0 : -1.0;
+        h.dist = sgn * r;
+        const double sc = sgn / r;
+        h.n = v3(R[0] * dl.x + R[1] * dl.y + R[2] * dl.z, R[3] * dl.x + R[4] * dl.y + R[5] * dl.z, R[6] * dl.x + R[7] * dl.y + R[8] * dl.z) * sc;
+    }
+    return h;
+}
+RD V3 sphere_centre_slot(const double* sl, const DevSpheres* __restrict__ S, int sp) {
+    const double* ro = sl + KL_RO + S->slot[sp] * 12;
+    M3 R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.m[k] = ro[k];
+    return v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+}
+template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+
 // RECORD (the longer-horizon path, kinova_expand_kernel): instead of Jacobian rows the kernel leaves a per-sample-eval record in
 // `JAC` -- d tau / d(q, q_d, q_dd) as three 7 x 7 blocks and d dist / d q per sphere -- because PiecewiseBezierCurves columns
 // carry their own weight triples; the g rows are written as usual.
@@ -437,13 +501,19 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 continue;
             }
             const int jid = S->joint_id[sp];
-            const V3 point = sphere_centre(sl, S, sp, jid);
-            BoxBest best;
-            best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0;
-            for (int ob = 0; ob < O; ob++) box_candidate(boxes + ob, ob, point, best);
-            if (G != nullptr) G[row] = box_best_distance(best) - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
+            const V3 point = sphere_centre_slot(sl, S, sp);
+            double bkey = 1e300;
+            int bidx = 0;
+#pragma unroll 2
+            for (int ob = 0; ob < O; ob++) {
+                const double key = box_key(boxes + ob, point);
+                if (key < bkey) { bkey = key; bidx = ob; }  // strict: the first minimum wins (BoxCollisionAvoidance.cpp:305-308)
+            }
+            const BoxHit hit = box_hit(boxes + bidx, point);
+            if (G != nullptr) G[row] = hit.dist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
             if (DERIV) {
-                const SV Wr = box_gradient_wrench(boxes + best.idx, best, point, w0);
+                const V3 dw = hit.n * w0;
+                const SV Wr = SV{cross(point, dw), dw};  // diff . (w x (p - o)) = s_c . [p x diff ; diff]
 #pragma unroll
                 for (int c = 0; c < NV; c++) sl[KL_X + sp * NV + c] = (c < jid) ? dot(lds_sv(sl + KL_S + c * 6), Wr) : 0.0;
             }
@@ -453,24 +523,23 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             for (int sp = full; sp < ns; sp++) {
                 const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
                 const int jid = S->joint_id[sp];
-                const V3 point = sphere_centre(sl, S, sp, jid);
-                BoxBest best;
-                best.key = 1e38; best.d2 = 0.0; best.sign = 1.0; best.dl = v3(0, 0, 0); best.idx = 0x7fffffff;
-                for (int ob = g; ob < O; ob += KG) box_candidate(boxes + ob, ob, point, best);
-                double dist = (best.idx == 0x7fffffff) ? 1e19 : box_best_distance(best);
-#pragma unroll
-                for (int d = KG / 2; d >= 1; d >>= 1) {
-                    const double od = __shfl_xor(dist, d, KG);
-                    const int oi = __shfl_xor(best.idx, d, KG);
-                    const double o2 = __shfl_xor(best.d2, d, KG), os = __shfl_xor(best.sign, d, KG);
-                    const double ox = __shfl_xor(best.dl.x, d, KG), oy = __shfl_xor(best.dl.y, d, KG), oz = __shfl_xor(best.dl.z, d, KG);
-                    if (od < dist || (od == dist && oi < best.idx)) {
-                        dist = od; best.idx = oi; best.d2 = o2; best.sign = os; best.dl = v3(ox, oy, oz);
-                    }
+                const V3 point = sphere_centre_slot(sl, S, sp);
+                double bkey = 1e300;
+                int bidx = 0x7fffffff;
+                for (int ob = g; ob < O; ob += KG) {
+                    const double key = box_key(boxes + ob, point);
+                    if (key < bkey) { bkey = key; bidx = ob; }
                 }
-                if (g == 0 && G != nullptr) G[row] = dist - S->radius[sp];
+                // 8-lane arg-min, lowest box index on a tie: butterfly over i <-> 7 - i, i <-> i ^ 2, i <-> i ^ 1 (DPP)
+#define ARGMIN_STEP(CTRL) { const double ok_ = dpp_mov64<CTRL>(bkey); const int oi_ = dpp_mov32<CTRL>(bidx); \
+                            if (ok_ < bkey || (ok_ == bkey && oi_ < bidx)) { bkey = ok_; bidx = oi_; } }
+                ARGMIN_STEP(0x141) ARGMIN_STEP(0x4E) ARGMIN_STEP(0xB1)
+#undef ARGMIN_STEP
+                const BoxHit hit = box_hit(boxes + bidx, point);
+                if (g == 0 && G != nullptr) G[row] = hit.dist - S->radius[sp];
                 if (DERIV) {  // lane c = column c, with its own joint axis still in registers
-                    const SV Wr = box_gradient_wrench(boxes + best.idx, best, point, w0);
+                    const V3 dw = hit.n * w0;
+                    const SV Wr = SV{cross(point, dw), dw};
                     if (own) sl[KL_X + sp * NV + g] = (g < jid) ? dot(s, Wr) : 0.0;
                 }
             }

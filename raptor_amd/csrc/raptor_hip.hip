@@ -813,6 +813,7 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
         for (int s = 0; s < S.num_spheres; s++) {
             const int l = S.joint_id[s] - 1;
             if (S.ro_slot[l] < 0) S.ro_slot[l] = nslots++;
+            S.slot[s] = S.ro_slot[l];
         }
         if (nslots > 4 || S.num_spheres > 20) throw unsupported_error("Kinova kernel: at most 4 sphere-carrying links / 20 spheres");
     }
@@ -845,6 +846,8 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
         for (int k = 0; k < 3; k++) {
             boxes[o].center[k] = d->box_center[3 * o + k];
             boxes[o].size[k] = d->box_size[3 * o + k];
+            boxes[o].hs[k] = d->box_size[3 * o + k] / 2.0;  // BoxCollisionAvoidance.cpp:101
+            boxes[o].cl[k] = R[k] * d->box_center[3 * o] + R[3 + k] * d->box_center[3 * o + 1] + R[6 + k] * d->box_center[3 * o + 2];
         }
     }
 

@@ -50,10 +50,11 @@ RD M3 mul(const M3& A, const double* B) {  // A * B, B row-major 3x3 (uniform co
     return C;
 }
 RD V3 col(const M3& R, int j) { return V3{R.m[j], R.m[3 + j], R.m[6 + j]}; }
-// column j for a j that differs between lanes: selects, so that R stays in registers
+// column j for a j that differs between lanes: blended with 0 / 1 weights, so that R stays in registers (a select between
+// array elements is turned back into an indexed load from a stack copy by the compiler)
 RD V3 col_sel(const M3& R, int j) {
-    return V3{j == 0 ? R.m[0] : (j == 1 ? R.m[1] : R.m[2]), j == 0 ? R.m[3] : (j == 1 ? R.m[4] : R.m[5]),
-              j == 0 ? R.m[6] : (j == 1 ? R.m[7] : R.m[8])};
+    const double w0 = (j == 0) ? 1.0 : 0.0, w1 = (j == 1) ? 1.0 : 0.0, w2 = (j == 2) ? 1.0 : 0.0;
+    return V3{R.m[0] * w0 + R.m[1] * w1 + R.m[2] * w2, R.m[3] * w0 + R.m[4] * w1 + R.m[5] * w2, R.m[6] * w0 + R.m[7] * w1 + R.m[8] * w2};
 }
 
 // spatial motion vector [angular; linear] / force vector [moment; force], world frame at world origin
