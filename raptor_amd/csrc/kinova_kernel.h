@@ -28,17 +28,30 @@
 
 #define KG 8       // lanes per sample-eval
 #define K_EPB 32   // sample-evals per 256-lane workgroup
-// LDS layout per sample-eval, in doubles
-#define KL_S 0        // s_j            7 x 6
-#define KL_RO 42      // R, o of up to 4 sphere links   4 x 12
-#define KL_X 90       // phase 0 exchange (7 x 5), then IS/BtS (7 x 12) at +35; later sphere rows (ns x 7 <= 140)
-// stride per sample-eval (runtime, kinova_lds_stride): 90 + max(119, 7 ns) rounded up to 4 mod 16 doubles, so that the 8 groups
-// of a wave fall on disjoint LDS banks; 17 spheres -> 212 doubles -> 53 KB per workgroup -> three workgroups per CU
-__host__ __device__ inline int kinova_lds_stride(int ns) {
-    int need = KL_X + ((7 * ns > 119) ? 7 * ns : 119);
-    while (need % 16 != 4) need++;
-    return need;
-}
+#define K_WAVES (RAPTOR_BLOCK / 64)
+// LDS layout, in doubles.
+//   header (whole workgroup, staged once): sphere tables and the first KBOX_LDS boxes (what box_hit reads for a winner whose
+//   index differs between lanes; the box loop itself reads boxes through uniform scalar loads)
+#define KH_SPH 0                       // [sphere][4]: offset x y z, radius
+#define KH_SPI (4 * RAPTOR_MAX_SPHERES) // [sphere] two ints: joint id, pose slot
+#define KH_BOX (5 * RAPTOR_MAX_SPHERES) // [box][KBOX_STRIDE]: R (9), R^T centre (3), half sizes (3)
+#define KBOX_LDS 32
+#define KBOX_STRIDE 18                 // 15 used; 36 dwords apart: sixteen lanes on sixteen different boxes hit disjoint banks
+#define KH_SIZE (KH_BOX + KBOX_LDS * KBOX_STRIDE)
+//   then one area per wavefront (8 sample-evals, el = 0..7):
+//     el * KW_E  + KL_S   s_j                     7 x 6
+//     el * KW_E  + KL_RO  R, o of up to 4 sphere-carrying links   4 x 12
+//     KW_X + el * KW_XE   IS_j, BtS_j             7 x 12        (phase D -> E)
+//     KW_X + el * 7 ns    sphere rows [sphere][7] (after phase E: the rows of the wave's 8 sample-evals are CONTIGUOUS, in the
+//                         order they have in pg_pz, so the copy-out is a straight 16-byte-per-lane stream with no index arithmetic)
+//   the per-sample-eval strides (90, 84, 7 ns = 119 doubles) put the four groups of a 32-lane half on disjoint banks.
+#define KL_S 0
+#define KL_RO 42
+#define KW_E 90
+#define KW_X (8 * KW_E)
+#define KW_XE 84
+__host__ __device__ inline int kinova_wave_doubles(int ns) { return KW_X + 8 * ((7 * ns > KW_XE) ? 7 * ns : KW_XE); }
+__host__ __device__ inline int kinova_lds_doubles(int ns) { return KH_SIZE + K_WAVES * kinova_wave_doubles(ns); }
 
 RD void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -121,13 +134,6 @@ struct BoxBest {
 };
 RD double box_signed_distance(double d2, double sign) { return (d2 > 1e-12) ? sign * sqrt(d2) : 0.0; }  // SQUARE_ROOT_THRESHOLD
 RD double box_best_distance(const BoxBest& b) { return box_signed_distance(b.d2, b.sign); }
-RD V3 sphere_centre(const double* sl, const DevSpheres* __restrict__ S, int sp, int jid) {
-    const double* ro = sl + KL_RO + S->ro_slot[jid - 1] * 12;
-    M3 R;
-#pragma unroll
-    for (int k = 0; k < 9; k++) R.m[k] = ro[k];
-    return v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
-}
 RD void box_candidate(const DevBox* __restrict__ bx, int ob, V3 point, BoxBest& best) {
     M3 Rb;
 #pragma unroll
@@ -190,9 +196,10 @@ RD SV box_gradient_wrench(const DevBox* __restrict__ bx, const BoxBest& best, V3
 // square key = +-|diff|^2 (0 below SQUARE_ROOT_THRESHOLD), monotone in the reference's sign * sqrt(|diff|^2): strict `<` keeps
 // first-minimum-wins on ties, and only (key, index) live through the loop; the winner's direction is rebuilt once per sphere.
 RD void box_local(const double* __restrict__ R, const double* __restrict__ cl, const double* __restrict__ hs, V3 p, V3& lp, V3& e) {
-    lp.x = R[0] * p.x + (R[3] * p.y + (R[6] * p.z - cl[0]));
-    lp.y = R[1] * p.x + (R[4] * p.y + (R[7] * p.z - cl[1]));
-    lp.z = R[2] * p.x + (R[5] * p.y + (R[8] * p.z - cl[2]));
+    // (the centre is subtracted last: one scalar operand per instruction, no copies of box constants into vector registers)
+    lp.x = (R[0] * p.x + (R[3] * p.y + R[6] * p.z)) - cl[0];
+    lp.y = (R[1] * p.x + (R[4] * p.y + R[7] * p.z)) - cl[1];
+    lp.z = (R[2] * p.x + (R[5] * p.y + R[8] * p.z)) - cl[2];
     e = v3(fabs(lp.x) - hs[0], fabs(lp.y) - hs[1], fabs(lp.z) - hs[2]);
 }
 RD double box_key(const DevBox* __restrict__ bx, V3 p) {
@@ -201,21 +208,38 @@ RD double box_key(const DevBox* __restrict__ bx, V3 p) {
     const double emax = fmax(e.x, fmax(e.y, e.z));
     const double mx = fmax(e.x, 0.0), my = fmax(e.y, 0.0), mz = fmax(e.z, 0.0);
     const double d2o = mx * mx + (my * my + mz * mz), d2i = emax * emax;
-    const bool outside = emax > 0.0;
-    const double d2 = outside ? d2o : d2i;
-    const double key = outside ? d2o : -d2i;
-    return (d2 > 1e-12) ? key : 0.0;
+    const double key = (emax > 0.0) ? d2o : -d2i;
+    return (fabs(key) > 1e-12) ? key : 0.0;
+}
+// sqrt(x) and 1 / sqrt(x) together for x in the normal range (here 1e-12 < x < 1e4): the hardware reciprocal square root
+// refined by the coupled Newton steps a correctly rounded sqrt uses; both results are good to ~1 ulp
+RD void sqrt_rsqrt(double x, double& r, double& ir) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    e = fma(-h, g, 0.5);
+    h = fma(h, e, h);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    r = g;
+    ir = h + h;
 }
 struct BoxHit {
     double dist;  // signed distance (BoxCollisionAvoidance.cpp:300-303)
     V3 n;         // d dist / d point in world axes (zero below the threshold, :359-372)
 };
-RD BoxHit box_hit(const DevBox* __restrict__ bx, V3 p) {
+// b15 = R (9), R^T centre (3), half sizes (3) of the winning box: the head of a DevBox in HBM or its copy in the LDS header
+template <typename PTR>
+RD BoxHit box_hit(PTR b15, V3 p) {
     double R[9], cl[3], hs[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = bx->R[k];
+    for (int k = 0; k < 9; k++) R[k] = b15[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { cl[k] = bx->cl[k]; hs[k] = bx->hs[k]; }
+    for (int k = 0; k < 3; k++) { cl[k] = b15[9 + k]; hs[k] = b15[12 + k]; }
     V3 lp, e;
     box_local(R, cl, hs, p, lp, e);
     const double emax = fmax(e.x, fmax(e.y, e.z));
@@ -231,19 +255,63 @@ RD BoxHit box_hit(const DevBox* __restrict__ bx, V3 p) {
     h.dist = 0.0;
     h.n = v3(0, 0, 0);
     if (d2 > 1e-12) {
-        const double r = sqrt(d2), sgn = outside ? 1.0 : -1.0;
+        double r, ir;
+        sqrt_rsqrt(d2, r, ir);
+        const double sgn = outside ? 1.0 : -1.0;
         h.dist = sgn * r;
-        const double sc = sgn / r;
+        const double sc = sgn * ir;
         h.n = v3(R[0] * dl.x + R[1] * dl.y + R[2] * dl.z, R[3] * dl.x + R[4] * dl.y + R[5] * dl.z, R[6] * dl.x + R[7] * dl.y + R[8] * dl.z) * sc;
     }
     return h;
 }
-RD V3 sphere_centre_slot(const double* sl, const DevSpheres* __restrict__ S, int sp) {
-    const double* ro = sl + KL_RO + S->slot[sp] * 12;
+// one sphere of KinovaCustomizedConstraints: its tables from the LDS header, its centre from the published link pose
+struct SphereInfo {
+    int jid;
+    double radius;
+    V3 point;
+};
+RD SphereInfo sphere_info(const double* hdr, const double* se, int sp) {
+    SphereInfo si;
+    const int2 js = reinterpret_cast<const int2*>(hdr + KH_SPI)[sp];
+    const double* t = hdr + KH_SPH + 4 * sp;
+    const double* ro = se + KL_RO + js.y * 12;
     M3 R;
 #pragma unroll
     for (int k = 0; k < 9; k++) R.m[k] = ro[k];
-    return v3(ro[9], ro[10], ro[11]) + mul(R, v3(S->offset[sp][0], S->offset[sp][1], S->offset[sp][2]));
+    si.jid = js.x;
+    si.radius = t[3];
+    si.point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(t[0], t[1], t[2]));
+    return si;
+}
+// Wave-level copy-out: `len` doubles to dst (8-byte aligned), 16 bytes per lane, from a contiguous LDS run ...
+RD void wave_store_run(double* __restrict__ dst, const double* src, int len, int lane) {
+    const int head = (int)(((size_t)dst >> 3) & 1);  // 16-byte alignment of the run
+    if (head && lane == 0 && len > 0) dst[0] = src[0];
+    const int pairs = (len - head) >> 1;
+    double2* dst2 = reinterpret_cast<double2*>(dst + head);
+    for (int pidx = lane; pidx < pairs; pidx += 64) {
+        const int t = head + 2 * pidx;
+        dst2[pidx] = make_double2(src[t], src[t + 1]);
+    }
+    if (((len - head) & 1) && lane == 63) dst[len - 1] = src[len - 1];
+}
+// ... or the rows of pq_pz / pq_d_pz of `cnt` consecutive samples from ia on: w * identity per sample, 49 doubles each
+// (ArmourBezierCurves.cpp:147-151)
+RD void wave_store_diag(double* __restrict__ dst, const double* __restrict__ wsum, int ia, int order, int cnt, int lane) {
+    const int len = cnt * 49;
+    auto value = [&](int t) -> double {
+        const int el = t / 49, r = t - el * 49;
+        return (r % 8 == 0) ? wsum[(ia + el) * 3 + order] : 0.0;
+    };
+    const int head = (int)(((size_t)dst >> 3) & 1);
+    if (head && lane == 0 && len > 0) dst[0] = value(0);
+    const int pairs = (len - head) >> 1;
+    double2* dst2 = reinterpret_cast<double2*>(dst + head);
+    for (int pidx = lane; pidx < pairs; pidx += 64) {
+        const int t = head + 2 * pidx;
+        dst2[pidx] = make_double2(value(t), value(t + 1));
+    }
+    if (((len - head) & 1) && lane == 63) dst[len - 1] = value(len - 1);
 }
 template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
 
@@ -271,17 +339,59 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     constexpr int NV = 7;
     const int tid = threadIdx.x;
     const int g = tid & (KG - 1);
-    const int eg = tid >> 3;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int el = (tid >> 3) & 7;  // sample-eval within the wave
     const long long e0 = (long long)blockIdx.x * K_EPB;
-    const long long e = e0 + eg;
+    const long long ew0 = e0 + wv * 8;  // first sample-eval of this wave
+    const long long e = ew0 + el;
     const int N = T->N;
     const int ns = S->num_spheres;
-    const int KL_STRIDE = kinova_lds_stride(ns);
-    double* sl = lds + eg * KL_STRIDE;
+    const int O = S->num_obstacles;
+    const int rowlen = NV * ns;  // doubles of sphere rows per sample-eval
+    double* wbase = lds + KH_SIZE + wv * kinova_wave_doubles(ns);
+    double* se = wbase + el * KW_E;          // s_j, link poses
+    double* sx = wbase + KW_X + el * KW_XE;  // IS_j, BtS_j
+    double* srow = wbase + KW_X + el * rowlen;
+
+    // ---- stage the sphere tables and the first boxes in the LDS header (one barrier, at the start where the waves are aligned) ----
+    for (int t = tid; t < ns; t += RAPTOR_BLOCK) {
+        double* d = lds + KH_SPH + 4 * t;
+        d[0] = S->offset[t][0]; d[1] = S->offset[t][1]; d[2] = S->offset[t][2]; d[3] = S->radius[t];
+        reinterpret_cast<int2*>(lds + KH_SPI)[t] = make_int2(S->joint_id[t], S->slot[t]);
+    }
+    {
+        const int nb = O < KBOX_LDS ? O : KBOX_LDS;
+        for (int t = tid; t < nb * 15; t += RAPTOR_BLOCK) {
+            const int ob = t / 15, k = t - ob * 15;
+            lds[KH_BOX + ob * KBOX_STRIDE + k] = reinterpret_cast<const double*>(boxes + ob)[k];
+        }
+    }
+    __syncthreads();
+
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    // the run structure of this wave's sample-evals (wave-uniform): they start at sample i0 of decision vector b0
+    const int cntw = (int)((E - ew0 < 8) ? ((E - ew0 > 0) ? E - ew0 : 0) : 8);
+    const int i0 = __builtin_amdgcn_readfirstlane(i);
+    const long long b0 = ((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+
+    if (DERIV && !RECORD) {
+        // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43): they depend on the sample index only, so they
+        // leave first and drain while the dynamics are computed
+        int done = 0, ia = i0;
+        long long bb = b0;
+        while (done < cntw) {
+            const int cnt = (cntw - done < N - ia) ? cntw - done : N - ia;
+            const size_t rb = (size_t)bb * L.m;
+            wave_store_diag(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, wsum, ia, 0, cnt, lane);
+            wave_store_diag(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, wsum, ia, 1, cnt, lane);
+            done += cnt;
+            bb++;
+            ia = 0;
+        }
+    }
 
     if (e < E) {
-        const int i = (int)(e % N);
-        const long long b = e / N;
         const double* z = Z + b * L.n;  // L.n == 7 for ArmourBezierCurves
         const size_t rowbase = (size_t)b * L.m;
         const bool own = g < NV;  // lane 7 owns no joint
@@ -341,10 +451,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         scan_sv<4>(a, g);
         a.l = a.l + v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2]);
         if (own) {
-            lds_put(sl + KL_S + g * 6, s);
+            lds_put(se + KL_S + g * 6, s);
             const int slot = S->ro_slot[g];
             if (slot >= 0) {
-                double* ro = sl + KL_RO + slot * 12;
+                double* ro = se + KL_RO + slot * 12;
 #pragma unroll
                 for (int k = 0; k < 9; k++) ro[k] = Rw.m[k];
                 ro[9] = ow.x; ro[10] = ow.y; ro[11] = ow.z;
@@ -433,8 +543,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
             const SV gam = s * w2 + sd * (2.0 * w1) + psi * w0;
             const SV bet = s * w1 + sd * w0;
             if (own) {
-                lds_put(sl + KL_X + 35 + g * 12, IS);
-                lds_put(sl + KL_X + 35 + g * 12 + 6, BtS);
+                lds_put(sx + g * 12, IS);
+                lds_put(sx + g * 12 + 6, BtS);
             }
             wave_sync();
             // ---- phase E: lane g = column g of ptau_pz(i); the 7 lanes of a group write one 56-byte row per store, the
@@ -446,12 +556,12 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                     for (int j = 0; j < NV; j++) {
                         double dq, dv, da;
                         if (j < g) {
-                            const SV sj = lds_sv(sl + KL_S + j * 6);
+                            const SV sj = lds_sv(se + KL_S + j * 6);
                             dq = dot(sj, cq_);
                             dv = dot(sj, cv);
                             da = dot(sj, IS);
                         } else {
-                            const SV ISj = lds_sv(sl + KL_X + 35 + j * 12), BtSj = lds_sv(sl + KL_X + 35 + j * 12 + 6);
+                            const SV ISj = lds_sv(sx + j * 12), BtSj = lds_sv(sx + j * 12 + 6);
                             dq = dot(ISj, psi) + dot(BtSj, sd);
                             dv = 2.0 * dot(ISj, sd) + dot(BtSj, s);
                             da = dot(ISj, s);
@@ -471,63 +581,62 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 for (int j = 0; j < NV; j++) {
                     double d;
                     if (j < g) {
-                        d = dot(lds_sv(sl + KL_S + j * 6), p);
+                        d = dot(lds_sv(se + KL_S + j * 6), p);
                     } else {
-                        d = dot(lds_sv(sl + KL_X + 35 + j * 12), gam) + dot(lds_sv(sl + KL_X + 35 + j * 12 + 6), bet);
+                        d = dot(lds_sv(sx + j * 12), gam) + dot(lds_sv(sx + j * 12 + 6), bet);
                         if (j == g) d += M->armature[g] * w2 + M->damping[g] * w1;
                     }
                     trow[j * NV] = d;
                 }
             }
         }
-        wave_sync();  // the exchange area is reused for the sphere rows below
+        wave_sync();  // the IS / BtS area of the whole wave is reused for the sphere rows below
         KIN_PHASE_END(4, w0 + sv_sum(s))
 
         // ---- spheres: KinovaCustomizedConstraints.cpp:88-157, BoxCollisionAvoidance.cpp:92-137, 290-373 ----
         // Whole rounds give one sphere to each of the 8 lanes.  A short last round (17 spheres: one left over) would leave
         // seven lanes idle through the whole box loop, so its spheres are taken one at a time with the BOXES dealt to the
         // lanes and an 8-lane arg-min that keeps the reference's first-minimum-wins rule (lowest box index on a tie).
-        const int O = S->num_obstacles;
         const int full = (ns / KG) * KG, rem = ns - full;
         const bool split_tail = rem > 0 && rem * ((O + KG - 1) / KG + 2) < O;
         const int lim = split_tail ? full : ns;
+        const bool box_in_lds = O <= KBOX_LDS;
         for (int sp = g; sp < lim; sp += KG) {
             const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
             if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
                 if (G != nullptr) G[row] = 0.0;
                 if (DERIV)
 #pragma unroll
-                    for (int c = 0; c < NV; c++) sl[KL_X + sp * NV + c] = 0.0;
+                    for (int c = 0; c < NV; c++) srow[sp * NV + c] = 0.0;
                 continue;
             }
-            const int jid = S->joint_id[sp];
-            const V3 point = sphere_centre_slot(sl, S, sp);
+            const SphereInfo si = sphere_info(lds, se, sp);
             double bkey = 1e300;
             int bidx = 0;
 #pragma unroll 2
             for (int ob = 0; ob < O; ob++) {
-                const double key = box_key(boxes + ob, point);
+                const double key = box_key(boxes + ob, si.point);
                 if (key < bkey) { bkey = key; bidx = ob; }  // strict: the first minimum wins (BoxCollisionAvoidance.cpp:305-308)
             }
-            const BoxHit hit = box_hit(boxes + bidx, point);
-            if (G != nullptr) G[row] = hit.dist - S->radius[sp];  // KinovaCustomizedConstraints.cpp:145
+            const BoxHit hit = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx * KBOX_STRIDE), si.point)
+                                          : box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
+            if (G != nullptr) G[row] = hit.dist - si.radius;  // KinovaCustomizedConstraints.cpp:145
             if (DERIV) {
                 const V3 dw = hit.n * w0;
-                const SV Wr = SV{cross(point, dw), dw};  // diff . (w x (p - o)) = s_c . [p x diff ; diff]
+                const SV Wr = SV{cross(si.point, dw), dw};  // diff . (w x (p - o)) = s_c . [p x diff ; diff]
 #pragma unroll
-                for (int c = 0; c < NV; c++) sl[KL_X + sp * NV + c] = (c < jid) ? dot(lds_sv(sl + KL_S + c * 6), Wr) : 0.0;
+                for (int c = 0; c < NV; c++) srow[sp * NV + c] = (c < si.jid) ? dot(lds_sv(se + KL_S + c * 6), Wr) : 0.0;
             }
         }
         if (split_tail) {
 #pragma unroll 1
             for (int sp = full; sp < ns; sp++) {
                 const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
-                const int jid = S->joint_id[sp];
-                const V3 point = sphere_centre_slot(sl, S, sp);
+                const SphereInfo si = sphere_info(lds, se, sp);
                 double bkey = 1e300;
                 int bidx = 0x7fffffff;
                 for (int ob = g; ob < O; ob += KG) {
-                    const double key = box_key(boxes + ob, point);
+                    const double key = box_key(boxes + ob, si.point);
                     if (key < bkey) { bkey = key; bidx = ob; }
                 }
                 // 8-lane arg-min, lowest box index on a tie: butterfly over i <-> 7 - i, i <-> i ^ 2, i <-> i ^ 1 (DPP)
@@ -535,12 +644,13 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                             if (ok_ < bkey || (ok_ == bkey && oi_ < bidx)) { bkey = ok_; bidx = oi_; } }
                 ARGMIN_STEP(0x141) ARGMIN_STEP(0x4E) ARGMIN_STEP(0xB1)
 #undef ARGMIN_STEP
-                const BoxHit hit = box_hit(boxes + bidx, point);
-                if (g == 0 && G != nullptr) G[row] = hit.dist - S->radius[sp];
+                const BoxHit hit = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx * KBOX_STRIDE), si.point)
+                                              : box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
+                if (g == 0 && G != nullptr) G[row] = hit.dist - si.radius;
                 if (DERIV) {  // lane c = column c, with its own joint axis still in registers
                     const V3 dw = hit.n * w0;
-                    const SV Wr = SV{cross(point, dw), dw};
-                    if (own) sl[KL_X + sp * NV + g] = (g < jid) ? dot(s, Wr) : 0.0;
+                    const SV Wr = SV{cross(si.point, dw), dw};
+                    if (own) srow[sp * NV + g] = (g < si.jid) ? dot(s, Wr) : 0.0;
                 }
             }
         }
@@ -550,55 +660,22 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     if (KIN_STOP == 5) return;
 #endif
     if (!DERIV) return;
-    __syncthreads();
-    if (RECORD) {  // sphere gradients per joint, staged in LDS by the sphere rounds -> the records
-        const int cnt = (int)(((e0 + K_EPB < E) ? e0 + K_EPB : E) - e0);
-        const int per = ns * NV;
-        for (int t = tid; t < cnt * per; t += RAPTOR_BLOCK) {
-            const int el = t / per, r = t - el * per;
-            JAC[(size_t)(e0 + el) * KREC_STRIDE + KREC_G + r] = lds[el * KL_STRIDE + KL_X + r];
-        }
+    wave_sync();  // the rows of this wave's sample-evals are complete; no other wave touches them
+    const double* rows = wbase + KW_X;
+    if (RECORD) {  // sphere gradients per joint -> the records
+        for (int k = 0; k < cntw; k++)
+            for (int r = lane; r < rowlen; r += 64) JAC[(size_t)(ew0 + k) * KREC_STRIDE + KREC_G + r] = rows[k * rowlen + r];
         return;
     }
-
-    // ---- copy-out: contiguous runs per constraint block, 16 bytes per lane ----
-    const long long eend = (e0 + K_EPB < E) ? e0 + K_EPB : E;
-    long long ea = e0;
-    while (ea < eend) {  // one pass per decision vector touched by this workgroup
-        const long long b = ea / N;
-        const int ia = (int)(ea - b * N);
-        const long long eb = ((b + 1) * N < eend) ? (b + 1) * N : eend;
-        const int cnt = (int)(eb - ea);   // sample-evals in this run
-        const int el0 = (int)(ea - e0);   // first local slot
-        const size_t rowbase = (size_t)b * L.m;
-#pragma unroll 1
-        for (int region = 0; region < 4; region++) {
-            if (region == 2) continue;  // the torque rows were written by phase E
-            const int per_e = (region == 3) ? ns * NV : NV * NV;
-            const int off = (region == 0) ? L.off_q : (region == 1) ? L.off_qd : (region == 2) ? L.off_tau : L.off_obs;
-            const int rows_per_e = (region == 3) ? ns : NV;
-            double* dst = JAC + (rowbase + off + (size_t)ia * rows_per_e) * NV;
-            const int len = cnt * per_e;
-            const int lds_off = KL_X;
-            auto value = [&](int t) -> double {
-                const int el = t / per_e;
-                const int r = t - el * per_e;
-                if (region < 2) {  // pq_pz / pq_d_pz are w * identity (ArmourBezierCurves.cpp:147-151)
-                    return (r % (NV + 1) == 0) ? wsum[(ia + el) * 3 + region] : 0.0;
-                }
-                return lds[(el0 + el) * KL_STRIDE + lds_off + r];
-            };
-            const int head = (int)(((size_t)dst >> 3) & 1);  // 16-byte alignment of the run
-            if (head && tid == 0 && len > 0) dst[0] = value(0);
-            const int pairs = (len - head) >> 1;
-            double2* dst2 = reinterpret_cast<double2*>(dst + head);
-            for (int pidx = tid; pidx < pairs; pidx += RAPTOR_BLOCK) {
-                const int t = head + 2 * pidx;
-                dst2[pidx] = make_double2(value(t), value(t + 1));
-            }
-            if (((len - head) & 1) && tid == RAPTOR_BLOCK - 1) dst[len - 1] = value(len - 1);
-        }
-        ea = eb;
+    // ---- copy-out of the obstacle rows: one contiguous run per decision vector touched by this wave, 16 bytes per lane ----
+    int done = 0, ia = i0;
+    long long bb = b0;
+    while (done < cntw) {
+        const int cnt = (cntw - done < N - ia) ? cntw - done : N - ia;
+        wave_store_run(JAC + ((size_t)bb * L.m + L.off_obs + (size_t)ia * ns) * NV, rows + done * rowlen, cnt * rowlen, lane);
+        done += cnt;
+        bb++;
+        ia = 0;
     }
 }
 

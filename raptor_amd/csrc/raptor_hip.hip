@@ -415,12 +415,12 @@ template <bool DERIV, bool RECORD = false>
 void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, hipStream_t st) {
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
-    const size_t lds_bytes = (size_t)K_EPB * kinova_lds_stride(p.hspheres.num_spheres) * sizeof(double);
+    const size_t lds_bytes = (size_t)kinova_lds_doubles(p.hspheres.num_spheres) * sizeof(double);
     static bool attr_set[2] = {false, false};  // one flag pair per instantiation of this template
     if (!attr_set[DERIV]) {  // > 64 KiB of dynamic LDS needs the opt-in
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_fused_kernel<DERIV, RECORD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(K_EPB * kinova_lds_stride(RAPTOR_MAX_SPHERES) * sizeof(double))));
+                                      (int)(kinova_lds_doubles(RAPTOR_MAX_SPHERES) * sizeof(double))));
         attr_set[DERIV] = true;
     }
     const unsigned grid = (unsigned)((E + K_EPB - 1) / K_EPB);
