@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: RNEA + d(tau)/dz sample-evals/s (fp64).
 
-  python bench.py --gpus N --steps K --warmup W [--workload kinova|talos|g1|digit]
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--workload kinova|kinova_lh|talos|g1|digit]
+
+N > 1 without a launcher (WORLD_SIZE unset): this process starts N ranks itself (`python -m torch.distributed.run`, as a child
+process, before anything here touches the GPU) and exits with their code; it refuses to run when fewer than N GPUs are visible.
+Under an external launcher (WORLD_SIZE set) it is one rank: one process per GPU, RCCL through torch.distributed ("nccl").
 
 Default workload = BASELINE.json configs[1] (Kinova): a *step* is one pass of the hot path (eval_g + eval_jac_g, i.e.
-raptor_eval_batch with G|JAC) over one batch of B = 4096 decision vectors x N = 128 time samples = 524 288
-sample-evals, inputs and outputs resident in HBM.  With N GPUs every rank evaluates its own batch (multi-start
-problems are independent: weak scaling, no data-path collective).  `--workload talos|g1` runs the legged single-step
-problem (configs[2] / configs[4] shard: 1024 problems x 14 samples per GPU) the same way.
+raptor_eval_batch with G|JAC) over one batch of B = 4096 decision vectors x N = 128 time samples = 524 288 sample-evals,
+inputs and outputs resident in HBM.  With N GPUs every rank evaluates its own batch (multi-start problems are independent:
+weak scaling, no data-path collective in the evaluation).  The path's one exchange step -- the gather of per-problem records
+after a multi-start sweep (BASELINE.json configs[4]: Unitree-G1, 8192 problems over the GPUs of the node) -- is measured in the
+same run as the record `multistart` (evaluation + record + ONE all_gather_into_tensor inside the timed region).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events recorded on the
-evaluation stream inside the timed region; `cpu_baseline` is the CPU oracle (a restatement of the reference: kind
-"port") timed on one host core over a bounded sample of the same batch, which doubles as a last parity check.
+Prints ONE JSON line (rank 0).  `roofline` is for the longest kernel, timed live with HIP events recorded on the evaluation
+stream inside the timed region; `cpu_baseline` is the CPU oracle (a restatement of the reference: kind "port") timed on the
+host cores over a bounded sample of the same batch (1 core like the reference's serial loop, and all cores as independent
+processes over z), which doubles as a last parity check.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
+SPINUP_SECONDS = 0.25     # untimed passes before the W warm-up steps: the GPU needs ~50 ms of load to reach its clocks
 
 
 class Kinova:
@@ -41,9 +49,9 @@ class Kinova:
     # algorithmic flops per sample-eval: RNEA 550*nv + analytic derivatives ~7e3 + contraction 2058
     # + sphere FK / box distances ~25e3
     flops_per_se = 550 * 7 + 7000 + 2058 + 25000
-    dominant = 0  # index of the dominant kernel among the timed pair
     kernels = ["kinova_fused_kernel<true> (trajectory + RNEA + d tau/dz + limit rows + sphere/box rows)", None]
-    pmc_key = "kinova_fused_kernel<true>"
+    pmc_keys = ["kinova_fused_kernel<true, false>", None]
+    bound = "fp64-valu issue (VALU-busy from the PMC pass beside it); the HBM fraction is reported because the kernel's only traffic is its output"
     z_scale = 1.0
     workload = ("Kinova-gen3 7-DoF ArmourBezier, 128 Chebyshev samples x 4096 random z in U(-1,1)^7 per GPU, "
                 "eval_g+eval_jac_g (joint/velocity/torque limits + 17 spheres vs 10 boxes in reach), no solver")
@@ -66,10 +74,10 @@ class KinovaLongerHorizon:
     rows = 21 + 17
     bytes_per_se = rows * (84 + 1) * 8
     flops_per_se = 550 * 7 + 3 * 2 * 7 * 7 * 84 + 7000 + 25000  # RNEA + the reference's three 7x7 . 7x84 products + derivatives + spheres
-    dominant = 1
     kernels = ["kinova_fused_kernel<true,RECORD> (trajectory + RNEA + d tau/d(q,v,a) blocks + sphere gradients per joint + g rows)",
                "kinova_expand_kernel (pg_pz rows in Optimizer order from the per-sample records and the column weights)"]
-    pmc_key = "kinova_expand_kernel"
+    pmc_keys = ["kinova_fused_kernel<true, true>", "kinova_expand_kernel"]
+    bound = "hbm"
     z_scale = 1.0
     workload = ("Kinova-gen3 7-DoF PiecewiseBezierCurves degree 4 (84 variables), 100 uniform samples x 1024 random z in U(-1,1)^84 per GPU, "
                 "eval_g+eval_jac_g (joint/velocity/torque limits + 17 spheres vs 10 boxes in reach), no solver")
@@ -95,10 +103,10 @@ class Legged:
     batch = 1024
     bytes_per_se = None                   # 8 (rows / N) (n + 1): every row the expand kernel writes, once, g and pg_pz
     flops_per_se = 230000                 # SURVEY.md 8d total for Talos / G1 as the reference does it
-    dominant = 1
     kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows) + legged_period_kernel (reset-map rows)",
                "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
-    pmc_key = "legged_expand_kernel"
+    pmc_keys = ["legged_core_kernel<16, true>", "legged_expand_kernel"]
+    bound = "hbm"
     z_scale = 0.1  # TalosSingleStep.cpp:61
 
     def __init__(self, which):
@@ -121,11 +129,11 @@ class Digit:
     batch = 4096
     bytes_per_se = None                   # 8 (rows / N) (n + 1) over the expand kernel's rows (torque, joint limits, contact, customized)
     flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
-    dominant = 1
     kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
                "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
                "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
-    pmc_key = "legged_expand_kernel"
+    pmc_keys = ["legged_core_kernel<32, true>", "legged_expand_kernel"]
+    bound = "hbm"
     z_scale = 0.1  # DigitSingleStep.cpp:75
     workload = ("Digit-v3 single-step gait, nv=36 (6 floating + 12 actuated + 18 closed-loop), Bezier degree 5, "
                 "14 Chebyshev samples x 4096 random z in 0.1*U(-1,1)^132 per GPU, eval_g+eval_jac_g "
@@ -139,9 +147,11 @@ class Digit:
 
 
 WORKLOADS = {"kinova": Kinova, "kinova_lh": KinovaLongerHorizon, "talos": lambda: Legged("talos"), "g1": lambda: Legged("g1"), "digit": Digit}
+MULTISTART_TOTAL = 8192   # BASELINE.json configs[4]
+MULTISTART_WEAK = 1024    # ... = 1024 problems per GPU on the 8-GPU node
 
 
-def main() -> None:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -150,25 +160,54 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Digit record appended to the default (Kinova) line")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loop (profiling runs: keeps the kernel statistics to the batch launches)")
+    ap.add_argument("--no-multistart", action="store_true", help="skip the G1 multi-start sweep record (configs[4])")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loops (profiling runs: keeps the kernel statistics to the batch launches)")
     ap.add_argument("--no-eval-h", action="store_true", help="skip the eval_h record of the Kinova line")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--no-spinup", action="store_true", help="skip the untimed clock spin-up before the warm-up steps")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-worker", nargs=3, metavar=("WORKLOAD", "ZFILE", "OUT"), help=argparse.SUPPRESS)
+    return ap.parse_args()
 
+
+def main() -> None:
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(*args.cpu_worker)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # no launcher: start the ranks ourselves, as a child process, before this process has touched the GPU
+        import torch
+
+        visible = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime
+        if visible < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {visible} GPU(s) visible: refusing to report a smaller run")
+        from raptor_amd.launch import run_ranks
+
+        sys.exit(run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    run_rank(args)
+
+
+def run_rank(args) -> None:
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    from raptor_amd.launch import dist_env
+    from raptor_amd.multistart import shard_range, timed_sweep
+
+    rank, local_rank, world = dist_env()
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU {local_rank}")
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import raptor_amd
     from raptor_amd import _capi as A
@@ -180,6 +219,18 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def spinup(step):
+        """Untimed passes until the GPU has been busy for SPINUP_SECONDS (clock ramp); returns how many ran."""
+        if args.no_spinup:
+            return 0
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < SPINUP_SECONDS:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            n += 10
+        return n
 
     def run(W, batch, cpu_seconds):
         """W over `args.steps` timed steps; returns the JSON record (rank 0) or None."""
@@ -196,6 +247,7 @@ def main() -> None:
         def step():
             prob.eval_device(Z.data_ptr(), B, flags, G.data_ptr(), J.data_ptr(), stream)
 
+        spun = spinup(step)
         for _ in range(args.warmup):
             step()
         barrier()
@@ -206,24 +258,43 @@ def main() -> None:
         barrier()
         elapsed = time.perf_counter() - t0
         n_prof, k0_ms, k1_ms = prob.profile_end()
+        per_rank_ms, ranks_seen = [1e3 * elapsed / args.steps], 1
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            allt = torch.empty(world, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allt, mine)            # RCCL: every rank's own time
+            one = torch.ones(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)          # RCCL: how many ranks took part
+            per_rank_ms = [1e3 * float(x) / args.steps for x in allt.cpu()]
+            ranks_seen = int(round(float(one.item())))
+            elapsed = float(allt.max().item())
         if rank != 0:
             return None
         sample_evals = B * W.samples
         assert bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all())
         kms = [k0_ms, k1_ms]
-        dom_ms = kms[W.dominant]
-        dom_s = dom_ms * 1e-3
+        dom = 0 if k0_ms >= k1_ms else 1   # the roofline is quoted on the longest kernel (group) of the evaluation
         tot_s = (k0_ms + k1_ms) * 1e-3
-        # legged workloads: the dominant (expand) kernel writes every block but the reset map, which legged_period_kernel
+        # legged workloads: the expand kernel writes every block but the reset map, which legged_period_kernel
         # writes once per z inside the first kernel group
-        exp_rows = prob.m - (prob.block_offsets[-1] - prob.block_offsets[-2] if not getattr(W, "name", "").startswith("kinova") else 0)
+        exp_rows = prob.m - (prob.block_offsets[-1] - prob.block_offsets[-2] if not W.name.startswith("kinova") else 0)
         bytes_per_se = W.bytes_per_se or 8.0 * exp_rows / W.samples * (prob.n + 1)
         alg_bytes = sample_evals * bytes_per_se
         ms_per_step = 1e3 * elapsed / args.steps
+
+        def hbm_line(k):
+            """HBM roofline entry of timed kernel (group) k: the algorithmic output bytes belong to the kernel that writes them."""
+            ms = kms[k]
+            writes_rows = (k == 0) if W.kernels[1] is None else (k == 1)
+            if not writes_rows or ms <= 0:
+                return {"kernel": W.kernels[k], "kernel_ms": ms, "achieved": None, "frac": None,
+                        "note": "this kernel group leaves compact per-sample records, not the rows: its roof is fp64 issue, see roofline_fp64 / valu"}
+            gbs = alg_bytes / (ms * 1e-3) / 1e9
+            return {"kernel": W.kernels[k], "kernel_ms": ms, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+
+        lines = [hbm_line(k) for k in (0, 1) if W.kernels[k]]
+        rows_k = 0 if W.kernels[1] is None else 1
+        traffic, pmc_note = pmc_traffic(W.pmc_keys[rows_k], W.name)
         out = {
             "metric": "RNEA+dtau/dz sample-evals/sec (fp64)",
             "value": world * sample_evals * args.steps / elapsed,
@@ -240,49 +311,82 @@ def main() -> None:
             "config": {
                 "workload": W.workload,
                 "batch_per_gpu": B, "samples": W.samples, "n": prob.n, "m": prob.m,
-                "flags": "G|JAC", "parallelism": f"multi-start x{world} (independent batches, no collective)",
+                "flags": "G|JAC", "parallelism": f"multi-start x{world} (independent batches, no collective in the evaluation; the gather step is the `multistart` record)",
+                "untimed_spinup_steps": spun,
             },
+            "ranks_seen_by_rccl": ranks_seen,
+            "per_rank_ms_per_step": per_rank_ms,
             "eval_jac_g_latency_ms_batch": ms_per_step,
             "roofline": {
-                "kernel": W.kernels[W.dominant],
+                "kernel": W.kernels[rows_k],
                 "bound": "hbm",
-                "achieved": alg_bytes / dom_s / 1e9 if dom_s > 0 else None,
+                "binding_roof": W.bound,
+                "achieved": lines[rows_k if len(lines) > 1 else 0]["achieved"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": (alg_bytes / dom_s / 1e9) / HBM_PEAK_GBS if dom_s > 0 else None,
-                "traffic": pmc_traffic(W.pmc_key, W.name),
-                "kernel_ms": dom_ms,
+                "frac": lines[rows_k if len(lines) > 1 else 0]["frac"],
+                "traffic": traffic,
+                "traffic_source": pmc_note,
+                "kernel_ms": kms[rows_k],
+                "longest_kernel": W.kernels[dom],
                 "launches_timed": n_prof,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_sample_eval": bytes_per_se,
+                "per_kernel": lines,
+                "mfma": "none: no matrix-core instruction anywhere in the library (the d tau/dz contraction has rank-1 column structure, DESIGN.md 3.1)",
             },
             "roofline_fp64": {
                 "kernel": "all kernels of one evaluation",
                 "bound": "fp64-valu",
+                "kind": "reference-equivalent: flops the reference's algorithm spends on the same work (SURVEY.md 8d), not flops executed; "
+                        "the kernels execute far fewer (analytic derivatives, no dense products)",
                 "achieved": sample_evals * W.flops_per_se / tot_s / 1e12 if tot_s > 0 else None,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (sample_evals * W.flops_per_se / tot_s / 1e12) / FP64_PEAK_TFLOPS if tot_s > 0 else None,
                 "algorithmic_flops_per_sample_eval": W.flops_per_se,
+                "valu": pmc_valu(W, kms),
             },
             "kernels_ms": {k: v for k, v in zip(W.kernels, kms) if k},
         }
-        # single-problem latency (the Ipopt-driven use: one z, eval_g + eval_jac_g, results left in HBM), host-synchronised per call
         if not args.no_latency:
-            for _ in range(5):
-                prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
-            torch.cuda.synchronize()
-            reps = 200
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
-                torch.cuda.synchronize()
-            out["single_problem_eval_jac_g_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
+            out.update(latency_records(prob, Z, G, J, flags, stream))
         if world == 1 and cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(W, Z.cpu().numpy(), cpu_seconds, G, J)
         if W.name.startswith("kinova") and world == 1 and not args.no_eval_h:
             out["eval_h"] = eval_h_record(W, prob, Z, B, cpu_seconds > 0)
         return out
+
+    def latency_records(prob, Z, G, J, flags, stream):
+        """The Ipopt-driven use: one z per call, host-synchronised.  (a) results left in HBM (raptor_eval_batch);
+        (b) the adapter's real call, raptor_eval_batch_host: host buffers in and out, PCIe included."""
+        rec = {}
+        for _ in range(5):
+            prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
+        torch.cuda.synchronize()
+        reps = 200
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            prob.eval_device(Z.data_ptr(), 1, flags, G.data_ptr(), J.data_ptr(), stream)
+            torch.cuda.synchronize()
+        rec["single_problem_eval_jac_g_latency_ms"] = 1e3 * (time.perf_counter() - t1) / reps
+        import ctypes
+        import numpy as np
+
+        z1 = np.ascontiguousarray(Z[:1].cpu().numpy())
+        g1, j1 = np.empty(prob.m), np.empty((prob.m, prob.n))  # caller-owned buffers, reused like the adapter's members
+        dp = ctypes.POINTER(ctypes.c_double)
+        fn, args_ = prob.api.fn("eval_batch_host"), (prob.handle, z1.ctypes.data_as(dp), 1, flags, g1.ctypes.data_as(dp), j1.ctypes.data_as(dp))
+        for _ in range(5):
+            prob.api.check(fn(*args_))
+        reps = 200
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn(*args_)
+        rec["single_problem_eval_jac_g_latency_ms_host"] = 1e3 * (time.perf_counter() - t1) / reps
+        assert np.array_equal(g1, G[0].cpu().numpy()) or float(np.max(np.abs(g1 - G[0].cpu().numpy()))) < 1e-9
+        rec["single_problem_host_bytes"] = 8 * (prob.n + prob.m * (prob.n + 1))
+        return rec
 
     def eval_h_record(W, prob, Z, B, with_cpu):
         """Optimizer::eval_h for the same batch (KinovaOptimizer runs with exact Hessians): one fused kernel per call,
@@ -323,7 +427,7 @@ def main() -> None:
         if armour:
             # as the reference does it: second-order tensors + contraction + sphere Hessians ~ 1.2e5 flops / sample-eval
             tf = B * W.samples * 1.2e5 / (ms * 1e-3) / 1e12
-            rec["roofline_fp64"] = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            rec["roofline_fp64"] = {"bound": "fp64-valu", "kind": "reference-equivalent", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf / FP64_PEAK_TFLOPS, "algorithmic_flops_per_sample_eval": 1.2e5}
         if not args.no_latency:  # the Ipopt-driven use: one z per call, host-synchronised
             reps = 100
@@ -354,12 +458,71 @@ def main() -> None:
             rec["rel_err_vs_oracle"] = err
         return rec
 
-    out = run(WORKLOADS[args.workload](), args.batch, 0.0 if args.no_cpu_baseline else args.cpu_seconds)
-    if args.workload == "kinova" and not args.no_secondary:
+    def multistart_record():
+        """BASELINE.json configs[4]: the Unitree-G1 multi-start sweep.  MULTISTART_TOTAL problems (the same set on every rank,
+        seeded) block-partitioned over the ranks; one sweep = this rank's block through eval_g + eval_jac_g, the per-problem
+        record {worst violation, feasible} (Optimizer.cpp:374-378) and ONE all-gather of the records (RCCL), all inside the
+        timed region.  Strong scaling: the total is fixed.  The weak figure (MULTISTART_WEAK problems per GPU) is measured too."""
+        W = Legged("g1")
+        keep = []
+        prob = W.build(hip, keep)
+        lb, ub = (torch.from_numpy(x).cuda() for x in prob.bounds())
+        stream = torch.cuda.current_stream().cuda_stream
+        flags = A.EVAL_G | A.EVAL_JAC
+        rec = {"kernels": W.kernels}
+        for key, total in (("strong", MULTISTART_TOTAL), ("weak", MULTISTART_WEAK * world)):
+            gen = torch.Generator(device="cpu").manual_seed(20250523 + 5)
+            Z_all = (W.z_scale * (torch.rand(total, prob.n, generator=gen, dtype=torch.float64) * 2 - 1)).cuda()
+            lo, hi = shard_range(total, world, rank)
+            per = -(-total // world)
+            G = torch.empty(per, prob.m, dtype=torch.float64, device="cuda")
+            J = torch.empty(per, prob.m, prob.n, dtype=torch.float64, device="cuda")
+
+            def evaluate(Zb):
+                prob.eval_device(Zb.data_ptr(), Zb.shape[0], flags, G.data_ptr(), J.data_ptr(), stream)
+                return G[:Zb.shape[0]]
+
+            spinup(lambda: evaluate(Z_all[lo:hi]))
+            r = timed_sweep(evaluate, Z_all, lb, ub, args.steps, args.warmup, sync=torch.cuda.synchronize)
+            # the evaluation alone (no record, no collective), for the split of the sweep time
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                evaluate(Z_all[lo:hi])
+            barrier()
+            ev = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(ev, op=dist.ReduceOp.MAX)
+            sweep_ms = 1e3 * r["elapsed_s"] / args.steps
+            eval_ms = 1e3 * float(ev.item()) / args.steps
+            rec[key] = {
+                "problems_total": total, "problems_per_gpu": per, "samples": W.samples, "n": prob.n, "m": prob.m,
+                "value": total * W.samples * args.steps / r["elapsed_s"], "unit": "sample-evals/s",
+                "ms_per_sweep": sweep_ms, "ms_evaluation_only": eval_ms, "ms_record_and_gather": max(sweep_ms - eval_ms, 0.0),
+                "per_rank_ms_per_sweep": [1e3 * x / args.steps for x in r["per_rank_s"]],
+                "ranks_seen_by_rccl": r["ranks_seen"],
+                "gathered_records": int(r["violation"].numel()), "feasible": int(r["feasible"].sum().item()),
+                "collective": "all_gather_into_tensor of one double per problem (RCCL)" if world > 1 else "none (one rank)",
+                "scaling": key,
+            }
+            del Z_all, G, J
+        rec["workload"] = ("Unitree-G1 single-step gait, 729 rows x 108 variables, 14 Chebyshev samples; "
+                           f"{MULTISTART_TOTAL} problems over {world} GPU(s) (strong) and {MULTISTART_WEAK} per GPU (weak), eval_g+eval_jac_g, "
+                           "Jacobians stay on the GPU that produced them")
+        return rec if rank == 0 else None
+
+    cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    out = run(WORKLOADS[args.workload](), args.batch, cpu_s)
+    if args.workload == "kinova" and not args.no_secondary and world == 1:
         # the north-star target is quoted on Digit-v3 (BASELINE.json): measure it in the same run, as a secondary record
-        sec = run(WORKLOADS["digit"](), 0, 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 6.0))
+        sec = run(WORKLOADS["digit"](), 0, min(cpu_s, 6.0))
+        out["secondary"] = {"digit": {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "roofline_fp64", "kernels_ms",
+                                                          "single_problem_eval_jac_g_latency_ms", "single_problem_eval_jac_g_latency_ms_host",
+                                                          "cpu_baseline") if k in sec}}
+    if args.workload == "kinova" and not args.no_multistart:
+        ms = multistart_record()
         if out is not None:
-            out["secondary"] = {"digit": {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels_ms", "single_problem_eval_jac_g_latency_ms", "cpu_baseline") if k in sec}}
+            out["multistart"] = ms
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -367,20 +530,85 @@ def main() -> None:
         dist.destroy_process_group()
 
 
+def _pmc_file():
+    return os.path.join(ROOT, "profiles", "pmc_latest.json")
+
+
+def _pmc_stale():
+    """True when a kernel source is newer than the committed counter file (the counters then describe older code)."""
+    try:
+        t = os.path.getmtime(_pmc_file())
+        src = os.path.join(ROOT, "raptor_amd", "csrc")
+        return any(os.path.getmtime(os.path.join(src, f)) > t for f in os.listdir(src))
+    except OSError:
+        return True
+
+
 def pmc_traffic(key, workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
+    """HBM bytes per launch of the row-writing kernel from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
     collected with this same command in separate WRITE_SIZE / FETCH_SIZE runs); None when no such entry is present."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        d = json.load(open(_pmc_file()))
         k = d.get(workload + ":" + key) or d[key]
-        return k["WRITE_SIZE_bytes"] + k["FETCH_SIZE_bytes"]
+        note = "profiles/pmc_latest.json (separate rocprofv3 --pmc passes of this command)"
+        if _pmc_stale():
+            note += "; WARNING: a kernel source is newer than that file, the counters may describe older code"
+        return k["WRITE_SIZE_bytes"] + k["FETCH_SIZE_bytes"], note
+    except Exception:
+        return None, "no counter entry for this kernel in profiles/pmc_latest.json"
+
+
+def pmc_valu(W, kms):
+    """Executed-VALU utilisation of the two kernel groups from the committed SQ_INSTS_VALU pass: wave-instructions x 4 cycles
+    (a wave64 fp64 / 32-bit VALU instruction occupies its SIMD for 4 cycles) over the SIMD-cycles of the measured launch."""
+    try:
+        d = json.load(open(_pmc_file()))
     except Exception:
         return None
+    out = []
+    for key, ms in zip(W.pmc_keys, kms):
+        ent = (d.get(W.name + ":" + key) or d.get(key)) if key else None
+        if not ent or "SQ_INSTS_VALU" not in ent or ms <= 0:
+            continue
+        simd_cycles = 1024 * 2.4e9 * ms * 1e-3  # 256 CUs x 4 SIMDs at 2.4 GHz
+        out.append({"kernel": key, "valu_wave_instructions": ent["SQ_INSTS_VALU"], "valu_busy": ent["SQ_INSTS_VALU"] * 4 / simd_cycles,
+                    "executed_fp64_tflops_upper_bound": ent["SQ_INSTS_VALU"] * 64 * 2 / (ms * 1e-3) / 1e12})
+    return {"per_kernel": out, "stale": _pmc_stale()} if out else None
+
+
+def _cpu_cores():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)  # the GPU box exports its CPU share here (16 for one GPU)
+    return max(1, min(avail, cap) if cap > 0 else min(avail, 16))
+
+
+def cpu_worker(workload, zfile, outfile):
+    """One process of the all-cores CPU leg: the oracle over its own slice of z, timed."""
+    import numpy as np
+
+    from raptor_amd import _capi as A
+
+    W = WORKLOADS[workload]()
+    oracle = A.CApi(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_")
+    keep = []
+    po = W.build(oracle, keep)
+    Z = np.load(zfile)
+    po.eval_host(Z[:1])
+    t0 = time.perf_counter()
+    po.eval_host(Z)
+    json.dump({"nz": int(Z.shape[0]), "seconds": time.perf_counter() - t0}, open(outfile, "w"))
 
 
 def cpu_baseline(W, Zs, budget_s, G, J):
-    """The CPU oracle (restatement of the reference's serial per-sample loop), one host core, on the first few z
-    of the same batch; also used as a last check of the GPU results on exactly those z."""
+    """The CPU oracle (restatement of the reference's serial per-sample loop) on the first few z of the same batch.
+    Leg 1: one host core -- the reference's own execution model; also the last check of the GPU results on exactly those z.
+    Leg 2: all host cores, one oracle process per core over disjoint z (the reference's objects are not thread-safe; a
+    multi-start user would run processes) -- the fair "all of the CPU" figure."""
+    import numpy as np
+
     from raptor_amd import _capi as A
     import helpers as H
 
@@ -390,7 +618,7 @@ def cpu_baseline(W, Zs, budget_s, G, J):
     t0 = time.perf_counter()
     po.eval_host(Zs[:1])
     per_z = time.perf_counter() - t0
-    nz = int(max(1, min(len(Zs), budget_s / max(per_z, 1e-6))))
+    nz = int(max(1, min(len(Zs), 0.6 * budget_s / max(per_z, 1e-6))))
     t0 = time.perf_counter()
     Go, Jo = po.eval_host(Zs[:nz])
     dt = time.perf_counter() - t0
@@ -398,16 +626,41 @@ def cpu_baseline(W, Zs, budget_s, G, J):
     ej = H.rel_err(J[:nz].cpu().numpy(), Jo)
     if not (eg < 1e-9 and ej < 1e-9):
         raise SystemExit(f"GPU result differs from the oracle: g {eg:.2e} pg_pz {ej:.2e}")
-    return {
+    rec = {
         "value": nz * W.samples / dt,
         "unit": "sample-evals/s",
         "cores": 1,
         "kind": "port",
         "sample": f"first {nz} of the {len(Zs)} z of the same batch (x{W.samples} samples), eval_g+eval_jac_g, "
-                  f"oracle/liboracle.so (-O2, serial like the reference's per-sample loop); GPU rows for those z checked "
+                  f"oracle/liboracle.so (-O3, serial like the reference's per-sample loop); GPU rows for those z checked "
                   f"against it: rel err g {eg:.1e}, pg_pz {ej:.1e}",
         "seconds": dt,
+        "us_per_eval_jac_g": 1e6 * dt / nz,
     }
+    # leg 2: one process per core, each its own problem object and slice
+    cores = _cpu_cores()
+    if cores > 1:
+        per_core = int(max(1, min(len(Zs) // cores, 0.4 * budget_s / max(dt / nz, 1e-6))))
+        with tempfile.TemporaryDirectory() as tmp:
+            procs = []
+            for c in range(cores):
+                zf, of = os.path.join(tmp, f"z{c}.npy"), os.path.join(tmp, f"o{c}.json")
+                np.save(zf, Zs[c * per_core:(c + 1) * per_core])
+                procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", W.name, zf, of],
+                                               env=dict(os.environ, OMP_NUM_THREADS="1")), of))
+            t0 = time.perf_counter()
+            ok = all(p.wait() == 0 for p, _ in procs)
+            wall = time.perf_counter() - t0
+            if ok:
+                res = [json.load(open(of)) for _, of in procs]
+                slow = max(r["seconds"] for r in res)
+                rec["all_cores"] = {
+                    "value": sum(r["nz"] for r in res) * W.samples / slow,
+                    "unit": "sample-evals/s", "cores": cores, "host_cpus_visible": os.cpu_count(), "kind": "port",
+                    "sample": f"{per_core} z per process x {cores} processes (disjoint slices of the same batch), slowest process {slow:.2f} s, "
+                              f"wall clock including process start {wall:.2f} s",
+                }
+    return rec
 
 
 if __name__ == "__main__":

@@ -15,7 +15,13 @@
  *     Codes mirror the exception classes the reference throws (std::invalid_argument,
  *     std::runtime_error), no exception ever crosses this boundary;
  *   - "d_" pointers are device (HBM) pointers, everything else is host memory;
- *   - objects are not thread-safe, exactly like the reference's.
+ *   - objects are not thread-safe, exactly like the reference's.  A raptor_problem also owns
+ *     device scratch (per-sample records, partial results) shared by all of its entry points: every call on one problem
+ *     must be ordered after the previous one -- the same hip_stream, or an event / synchronisation between streams.
+ *     Enqueuing raptor_eval_batch on one stream and raptor_eval_costs / raptor_eval_h_batch / a *_host call for the SAME
+ *     problem on another without ordering them races on that scratch.  Different problems are independent.
+ *   - *_host entry points are synchronous: they stage through HBM on a private stream of the problem and wait for that
+ *     stream only (small transfers through a pinned buffer), never for the whole device.
  *
  * The same signatures are exported by the CPU oracle (oracle/liboracle.so) with the prefix
  * oracle_ instead of raptor_ (host pointers everywhere); the parity tests call both.

@@ -93,6 +93,38 @@ struct DevBuf {
 
 inline double deg2rad(double d) { return d * M_PI / 180.0; }  // Utils.h:17-19
 
+// What the *_host entry points need beside the device staging buffers: a private non-blocking stream (so that a host-buffer
+// call waits for its own work only, never for the device) and one pinned host buffer for transfers small enough to be
+// latency-bound (the Ipopt-driven single-problem calls); large batches go straight from / to the caller's pageable memory.
+struct HostStage {
+    hipStream_t st = nullptr;
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
+    static constexpr size_t kPinMax = (size_t)64 << 20;
+    static constexpr size_t kZeroCopyMax = (size_t)4 << 20;  // below this the kernels work on the pinned buffer itself
+    HostStage() {}
+    HostStage(const HostStage&) = delete;
+    HostStage& operator=(const HostStage&) = delete;
+    ~HostStage() {
+        if (pin) (void)hipHostFree(pin);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    hipStream_t stream() {
+        if (!st) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return st;
+    }
+    char* pinned(size_t bytes) {
+        if (bytes > pin_bytes) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            pin_bytes = 0;
+            HIP_CHECK(hipHostMalloc(&pin, bytes, hipHostMallocDefault));
+            pin_bytes = bytes;
+        }
+        return static_cast<char*>(pin);
+    }
+};
+
 }  // namespace
 
 struct raptor_model {
@@ -137,6 +169,7 @@ struct raptor_problem {
     int tplan_n = -1;
     // staging for the *_host entry points (grown on demand, reused)
     DevBuf<double> s_Z, s_G, s_J, s_a, s_b, s_c;
+    HostStage hs;
     // optional per-kernel HIP-event timing (raptor_profile_begin / _end)
     bool profiling = false;
     std::vector<hipEvent_t> ev;   // 3 per evaluation: before / after the evaluation kernel (third: reserved)
@@ -703,6 +736,25 @@ double* scratch_device_address() {
         g_scratch_addr[dev] = addr;
     }
     return g_scratch_addr[dev];
+}
+}  // namespace
+
+// Copy of up to two runs of doubles between HBM and the pinned, device-mapped host buffer of the *_host latency path: full-width
+// contiguous accesses (writes to fine-grained host memory are not combined in L2, so the evaluation kernels' own 8-byte row pieces
+// would each become a PCIe transaction), and no copy engine (a DMA copy costs ~0.1 ms here).
+__global__ __launch_bounds__(256) void copy2_kernel(double* __restrict__ d0, const double* __restrict__ s0, const long long n0,
+                                                    double* __restrict__ d1, const double* __restrict__ s1, const long long n1) {
+    const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long t = t0; t < n0; t += stride) d0[t] = s0[t];
+    for (long long t = t0; t < n1; t += stride) d1[t] = s1[t];
+}
+namespace {
+void launch_copy2(double* d0, const double* s0, size_t n0, double* d1, const double* s1, size_t n1, hipStream_t st) {
+    const size_t nmax = std::max(n0, n1);
+    if (nmax == 0) return;
+    const unsigned grid = (unsigned)std::min<size_t>((nmax + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy2_kernel, dim3(grid), dim3(256), 0, st, d0, s0, (long long)n0, d1, s1, (long long)n1);
+    HIP_CHECK(hipGetLastError());
 }
 }  // namespace
 
@@ -1556,13 +1608,39 @@ int raptor_eval_batch_host(raptor_problem* p, const double* Z, int B, unsigned f
     if (wg && !G) throw std::invalid_argument("G buffer is null");
     if (B == 0) return RAPTOR_OK;
     const size_t n = p->layout.n, m = p->layout.m;
-    p->s_Z.upload(Z, (size_t)B * n);
+    const size_t zb = (size_t)B * n * sizeof(double), gb = wg ? (size_t)B * m * sizeof(double) : 0,
+                 jb = jac ? (size_t)B * m * n * sizeof(double) : 0;
+    hipStream_t st = p->hs.stream();
+    const bool pin = zb + gb + jb <= HostStage::kPinMax;
+    char* h = pin ? p->hs.pinned(zb + gb + jb) : nullptr;
+    if (pin && zb + gb + jb <= HostStage::kZeroCopyMax) {
+        // latency path (one Ipopt-driven problem): no copy engine (a DMA copy costs ~0.1 ms each on this platform); a small
+        // kernel moves z in and the rows out through the pinned, device-mapped buffer with full-width accesses
+        std::memcpy(h, Z, zb);
+        char* dh = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&dh, h, 0));
+        p->s_Z.ensure((size_t)B * n);
+        if (wg) p->s_G.ensure((size_t)B * m);
+        if (jac) p->s_J.ensure((size_t)B * m * n);
+        launch_copy2(p->s_Z.p, (const double*)dh, (size_t)B * n, nullptr, nullptr, 0, st);
+        eval_device(*p, p->s_Z.p, B, flags, wg ? p->s_G.p : nullptr, jac ? p->s_J.p : nullptr, st);
+        launch_copy2((double*)(dh + zb), p->s_G.p, wg ? (size_t)B * m : 0, (double*)(dh + zb + gb), p->s_J.p, jac ? (size_t)B * m * n : 0, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (wg) std::memcpy(G, h + zb, gb);
+        if (jac) std::memcpy(JAC, h + zb + gb, jb);
+        return RAPTOR_OK;
+    }
+    p->s_Z.ensure((size_t)B * n);
     if (wg) p->s_G.ensure((size_t)B * m);
     if (jac) p->s_J.ensure((size_t)B * m * n);
-    eval_device(*p, p->s_Z.p, B, flags, wg ? p->s_G.p : nullptr, jac ? p->s_J.p : nullptr, nullptr);
-    HIP_CHECK(hipDeviceSynchronize());
-    if (wg) HIP_CHECK(hipMemcpy(G, p->s_G.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost));
-    if (jac) HIP_CHECK(hipMemcpy(JAC, p->s_J.p, (size_t)B * m * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (pin) std::memcpy(h, Z, zb);
+    HIP_CHECK(hipMemcpyAsync(p->s_Z.p, pin ? (const void*)h : (const void*)Z, zb, hipMemcpyHostToDevice, st));
+    eval_device(*p, p->s_Z.p, B, flags, wg ? p->s_G.p : nullptr, jac ? p->s_J.p : nullptr, st);
+    if (wg) HIP_CHECK(hipMemcpyAsync(pin ? (void*)(h + zb) : (void*)G, p->s_G.p, gb, hipMemcpyDeviceToHost, st));
+    if (jac) HIP_CHECK(hipMemcpyAsync(pin ? (void*)(h + zb + gb) : (void*)JAC, p->s_J.p, jb, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // this call's own work only: other streams of the process are not waited for
+    if (pin && wg) std::memcpy(G, h + zb, gb);
+    if (pin && jac) std::memcpy(JAC, h + zb + gb, jb);
     API_CATCH
 }
 
@@ -1795,14 +1873,38 @@ int raptor_eval_h_batch_host(raptor_problem* p, const double* Z, int B, const do
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
     const size_t n = p->layout.n, m = p->layout.m, nh = n * (n + 1) / 2;
-    p->s_Z.upload(Z, (size_t)B * n);
-    p->s_G.upload(lambda, (size_t)B * m);
-    if (obj_factor) p->s_a.upload(obj_factor, B);
+    const size_t zb = (size_t)B * n * sizeof(double), lb = (size_t)B * m * sizeof(double), ob = obj_factor ? (size_t)B * sizeof(double) : 0,
+                 hb = (size_t)B * nh * sizeof(double);
+    hipStream_t st = p->hs.stream();
+    const bool pin = zb + lb + ob + hb <= HostStage::kPinMax;
+    char* h = pin ? p->hs.pinned(zb + lb + ob + hb) : nullptr;
+    if (pin) {
+        std::memcpy(h, Z, zb);
+        std::memcpy(h + zb, lambda, lb);
+        if (obj_factor) std::memcpy(h + zb + lb, obj_factor, ob);
+    }
+    if (pin && zb + lb + ob + hb <= HostStage::kZeroCopyMax) {  // latency path: kernels on the device-mapped pinned buffer
+        char* dh = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&dh, h, 0));
+        const int rc = raptor_eval_h_batch(p, (const double*)dh, B, obj_factor ? (const double*)(dh + zb + lb) : nullptr,
+                                           (const double*)(dh + zb), (double*)(dh + zb + lb + ob), st);
+        if (rc != RAPTOR_OK) return rc;
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::memcpy(H, h + zb + lb + ob, hb);
+        return RAPTOR_OK;
+    }
+    p->s_Z.ensure((size_t)B * n);
+    p->s_G.ensure((size_t)B * m);
+    if (obj_factor) p->s_a.ensure(B);
     p->s_b.ensure((size_t)B * nh);
-    const int rc = raptor_eval_h_batch(p, p->s_Z.p, B, obj_factor ? p->s_a.p : nullptr, p->s_G.p, p->s_b.p, nullptr);
+    HIP_CHECK(hipMemcpyAsync(p->s_Z.p, pin ? (const void*)h : (const void*)Z, zb, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(p->s_G.p, pin ? (const void*)(h + zb) : (const void*)lambda, lb, hipMemcpyHostToDevice, st));
+    if (obj_factor) HIP_CHECK(hipMemcpyAsync(p->s_a.p, pin ? (const void*)(h + zb + lb) : (const void*)obj_factor, ob, hipMemcpyHostToDevice, st));
+    const int rc = raptor_eval_h_batch(p, p->s_Z.p, B, obj_factor ? p->s_a.p : nullptr, p->s_G.p, p->s_b.p, st);
     if (rc != RAPTOR_OK) return rc;
-    HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemcpy(H, p->s_b.p, (size_t)B * nh * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpyAsync(pin ? (void*)(h + zb + lb + ob) : (void*)H, p->s_b.p, hb, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (pin) std::memcpy(H, h + zb + lb + ob, hb);
     API_CATCH
 }
 

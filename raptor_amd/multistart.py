@@ -104,3 +104,45 @@ def select_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], cost: Calla
         masked = torch.where(feas, out[:, 1], torch.full_like(out[:, 1], float("inf")))
         best = int(torch.argmin(masked))  # first minimum: lowest problem index on a tie, on every rank alike
     return {"violation": out[:, 0], "feasible": feas, "cost": out[:, 1], "best": best}
+
+
+def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor,
+                steps: int, warmup: int, sync: Optional[Callable[[], None]] = None, constr_viol_tol: float = 1e-4, group=None) -> dict:
+    """The multi-start sweep as a measured job: `steps` timed passes of `evaluate_sharded` (own block evaluated, per-problem
+    record built, ONE all-gather) between barriers, after `warmup` untimed ones.  `sync` waits for this rank's device
+    (torch.cuda.synchronize on a GPU; None on the CPU).  Returns, identically on every rank,
+    {"elapsed_s": max over ranks, "per_rank_s": [...], "ranks_seen": all-reduced count of ranks, "violation", "feasible"}."""
+    import time
+
+    import torch.distributed as dist
+
+    on = dist.is_initialized()
+
+    def barrier():
+        if on:
+            dist.barrier(group)
+        if sync is not None:
+            sync()
+
+    out = None
+    for _ in range(max(warmup, 0)):
+        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev = out[0].device if out is not None else Z_all.device
+    mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    if on:
+        world = dist.get_world_size(group)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine, group=group)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    else:
+        allt = mine
+    per_rank = [float(x) for x in allt.cpu()]
+    return {"elapsed_s": max(per_rank), "per_rank_s": per_rank, "ranks_seen": int(round(float(one.item()))),
+            "violation": None if out is None else out[0], "feasible": None if out is None else out[1]}
