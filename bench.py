@@ -164,6 +164,7 @@ def parse_args():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loops (profiling runs: keeps the kernel statistics to the batch launches)")
     ap.add_argument("--no-eval-h", action="store_true", help="skip the eval_h record of the Kinova line")
     ap.add_argument("--no-spinup", action="store_true", help="skip the untimed clock spin-up before the warm-up steps")
+    ap.add_argument("--no-check", action="store_true", help=argparse.SUPPRESS)  # phase-stub builds (scripts/*_phases.sh) leave garbage rows
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-worker", nargs=3, metavar=("WORKLOAD", "ZFILE", "OUT"), help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -271,7 +272,7 @@ def run_rank(args) -> None:
         if rank != 0:
             return None
         sample_evals = B * W.samples
-        assert bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all())
+        assert args.no_check or (bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all()))
         kms = [k0_ms, k1_ms]
         dom = 0 if k0_ms >= k1_ms else 1   # the roofline is quoted on the longest kernel (group) of the evaluation
         tot_s = (k0_ms + k1_ms) * 1e-3

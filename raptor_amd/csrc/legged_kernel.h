@@ -106,6 +106,12 @@ RD double contact_row(int r, const double* lam, const double* p, double mu, doub
     }
 }
 
+// Phase accounting: -DLEG_STOP=k ends the kernel after phase k with a checksum store.  Measurement builds only.
+#ifdef LEG_STOP
+#define LEG_PHASE_END(k, expr) if (LEG_STOP == (k)) { rec[g] = (expr); return; }
+#else
+#define LEG_PHASE_END(k, expr)
+#endif
 template <int LG, bool DERIV>
 __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         x[15] = qd; x[16] = qdd; x[17] = rev ? 1.0 : 0.0;
     }
     wave_sync();
+    LEG_PHASE_END(1, q + qd + qdd + sq + cq + w0[0] + w0[1] + w0[2] + w1[0] + w1[1] + w1[2])
 
     // ---- phase A: world-frame kinematics from the planted foot out to this body (per-lane path) ----
     M3 Rw;
@@ -218,6 +225,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         ow = o;
     }
     const SV sd = crm(vprev, s);
+
+    LEG_PHASE_END(2, sv_sum(v) + sv_sum(a) + sv_sum(s) + sv_sum(sd) + Rw.m[0] + Rw.m[4] + Rw.m[8] + Rw.m[1] + Rw.m[5] + Rw.m[6] + ow.x + ow.y + ow.z)
 
     // ---- phase B: this body's inertia, momentum, wrench, Coriolis block (world frame, about the origin) ----
     InertiaO I;
@@ -285,6 +294,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #undef CUT
     }
 
+    LEG_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sd) + sv_sum(v) + sv_sum(a))
+
     // ---- phase D: values.  tau rows, q rows, contact rows; the same numbers go to the compact record ----
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
@@ -337,10 +348,26 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             gc[6] = -Ly * lam[2] - lam[4];
         }
     }
+    // The torso's lane and the swing foot's lane both need roll / pitch / yaw of a frame (three atan2 / asin evaluations of a
+    // few hundred instructions): they run that code together, once per wave, instead of one lane after the other.
     const bool is_torso = has_body && g == Q->torso_body;
+    const bool is_sf = Q->ncust > 0 && has_body && g == Q->sf_body;
+    M3 Rsf;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rsf.m[k] = 0.0;
+    V3 psf = v3(0, 0, 0);
+    V3 rpy = v3(0, 0, 0);
+    if (is_torso || is_sf) {
+        M3 Rf = Rw;
+        if (is_sf) {
+            Rsf = mul(Rw, Q->sf_R);
+            psf = ow + mul(Rw, v3(Q->sf_p[0], Q->sf_p[1], Q->sf_p[2]));
+            Rf = Rsf;
+        }
+        rpy = v3(atan2(-Rf.m[5], Rf.m[8]), safe_asin(Rf.m[2]), atan2(-Rf.m[1], Rf.m[0]));  // Transform::getRPY (Transform.cpp:379-390)
+    }
     if (is_torso) {
         // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
-        const V3 rpy = v3(atan2(-Rw.m[5], Rw.m[8]), safe_asin(Rw.m[2]), atan2(-Rw.m[1], Rw.m[0]));
         const V3 pd = v.l + cross(v.a, ow);
         const V3 rd = rpy_rates(Rw, v.a);
         const V3 al = a.a;  // gravity enters only the linear part of a0
@@ -364,24 +391,16 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     // customized block (DigitCustomizedConstraints.cpp:88-125 / TalosCustomizedConstraints.cpp:88-124): the swing foot's
     // lane evaluates this sample's rows from its own pose and the floating-base coordinates of the torso's lane
-    const bool is_sf = Q->ncust > 0 && has_body && g == Q->sf_body;
-    M3 Rsf;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rsf.m[k] = 0.0;
-    V3 psf = v3(0, 0, 0);
     if (Q->ncust > 0) {
         double X[12];
         {
-            const V3 rpy_t = v3(atan2(-Rw.m[5], Rw.m[8]), safe_asin(Rw.m[2]), atan2(-Rw.m[1], Rw.m[0]));
-            const double mine[6] = {ow.x, ow.y, ow.z, rpy_t.x, rpy_t.y, rpy_t.z};
+            const double mine[6] = {ow.x, ow.y, ow.z, rpy.x, rpy.y, rpy.z};
 #pragma unroll
             for (int k = 0; k < 6; k++) X[6 + k] = __shfl(mine[k], Q->torso_body, LG);
         }
         if (is_sf) {
-            Rsf = mul(Rw, Q->sf_R);
-            psf = ow + mul(Rw, v3(Q->sf_p[0], Q->sf_p[1], Q->sf_p[2]));
             X[0] = psf.x; X[1] = psf.y; X[2] = psf.z;
-            X[3] = atan2(-Rsf.m[5], Rsf.m[8]); X[4] = safe_asin(Rsf.m[2]); X[5] = atan2(-Rsf.m[1], Rsf.m[0]);
+            X[3] = rpy.x; X[4] = rpy.y; X[5] = rpy.z;
 #pragma unroll
             for (int k = 0; k < 6; k++) rec[Q->c_sf + k] = X[k];
             if (G != nullptr) {
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
     }
     if (!DERIV) return;
+    LEG_PHASE_END(4, sv_sum(F) + sv_sum(H) + I.m + I.xx + Qt[0] + sv_sum(sd) + sv_sum(v) + sv_sum(a) + tt)
 
     // ---- phase E: per-joint 6-vectors of the analytic derivative ----
     const SV psi = crm(a, s) + crm(v, sd);
@@ -506,6 +526,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             }
         }
     }
+
+    LEG_PHASE_END(5, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1])
 
     // ---- phase F2: row pass.  Lane = tree joint j (row), loop over actuator columns `it` and the joints k that move with
     // it.  One code path for both relations: with (A, U1, U2, U3) = (s_j; IS_k, cv_k, cq_k) when j is a strict ancestor of
