@@ -299,14 +299,26 @@ class Optimizer:
             M[iu] = h
             return M + np.triu(M, 1).T
 
+        # Ipopt's protocol for new_x: true on the FIRST callback at an x it has not shown the TNLP before, false on the callbacks
+        # that follow at the same x.  The reference's best-feasible-iterate bookkeeping depends on it (an eval_f and an eval_g at
+        # the same x, the second with new_x = false, complete one record: Optimizer.cpp:154-196, 380-421).
+        last = {"x": None}
+
+        def fresh(x):
+            x = np.asarray(x, dtype=np.float64)
+            if last["x"] is not None and last["x"].shape == x.shape and np.array_equal(last["x"], x):
+                return False
+            last["x"] = x.copy()
+            return True
+
         if self.enable_hessian:
-            hess_f = lambda x: unpack(self.eval_h(n, x, False, 1.0, m, np.zeros(m), True))  # noqa: E731
-            hess_g = lambda x, v: unpack(self.eval_h(n, x, False, 0.0, m, v, True))  # noqa: E731
+            hess_f = lambda x: unpack(self.eval_h(n, x, fresh(x), 1.0, m, np.zeros(m), True))  # noqa: E731
+            hess_g = lambda x, v: unpack(self.eval_h(n, x, fresh(x), 0.0, m, v, True))  # noqa: E731
         else:
             hess_f, hess_g = BFGS(), BFGS()
-        con = NonlinearConstraint(lambda x: self.eval_g(n, x, True, m), lb, ub,
-                                  jac=lambda x: self.eval_jac_g(n, x, False, m).reshape(m, n), hess=hess_g)
-        res = minimize(lambda x: self.eval_f(n, x, True), x0, jac=lambda x: self.eval_grad_f(n, x, False), hess=hess_f,
+        con = NonlinearConstraint(lambda x: self.eval_g(n, x, fresh(x), m), lb, ub,
+                                  jac=lambda x: self.eval_jac_g(n, x, fresh(x), m).reshape(m, n), hess=hess_g)
+        res = minimize(lambda x: self.eval_f(n, x, fresh(x)), x0, jac=lambda x: self.eval_grad_f(n, x, fresh(x)), hess=hess_f,
                        constraints=[con], method="trust-constr", options=dict(maxiter=max_iter, gtol=tol, xtol=1e-10, verbose=verbose))
         self.finalize_solution(n, res.x, m, self.eval_g(n, res.x, True, m), float(res.fun))
         return res

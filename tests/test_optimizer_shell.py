@@ -127,6 +127,39 @@ def test_solve_with_the_stand_in_solver(oracle, kinova):
     assert np.abs(opt.solution - q_des / s).max() < 1e-3
 
 
+def test_solve_follows_ipopts_new_x_protocol_and_restores_a_feasible_iterate(oracle, kinova, monkeypatch):
+    """solve() must flag new_x only on the first callback at an x (Ipopt's protocol): then an eval_f + eval_g pair at one x completes
+    a record and finalize_solution can fall back to the best feasible iterate (Optimizer.cpp:154-196, 675-701).  A stand-in
+    `minimize` visits a feasible point (f, g, grad, jac at the same x) and then returns an infeasible one."""
+    import scipy.optimize as so
+
+    keep = []
+    opt = kinova_optimizer(oracle, kinova, keep, q_des=np.full(7, 0.5))
+    feas, infeas = np.full(7, 0.2), np.full(7, 40.0)
+    seen = []
+    orig = {k: getattr(opt, k) for k in ("eval_f", "eval_g", "eval_grad_f", "eval_jac_g")}
+    for k, fn in orig.items():
+        monkeypatch.setattr(opt, k, (lambda name, f: (lambda n, x, new_x, *a: (seen.append((name, bool(new_x))), f(n, x, new_x, *a))[1]))(k, fn))
+
+    class Res:
+        pass
+
+    def fake_minimize(fun, x0, jac=None, hess=None, constraints=(), **kw):
+        con = constraints[0]
+        for x in (feas, infeas):
+            fun(x); con.fun(x); jac(x); con.jac(x)
+        r = Res()
+        r.x, r.fun = infeas, fun(infeas)
+        return r
+
+    monkeypatch.setattr(so, "minimize", fake_minimize)
+    opt.solve()
+    head = [s for s in seen[:8]]
+    assert head == [("eval_f", True), ("eval_g", False), ("eval_grad_f", False), ("eval_jac_g", False)] * 2
+    assert opt.ifFeasible and np.array_equal(opt.solution, feas)  # the infeasible result was replaced by the recorded feasible iterate
+    assert opt.final_constr_violation <= opt.constr_viol_tol
+
+
 @pytest.mark.gpu
 def test_solve_on_the_gpu_matches_the_oracle_run(oracle, hip, kinova):
     keep = []
