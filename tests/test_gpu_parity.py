@@ -172,12 +172,25 @@ def test_capsule_known_answers_and_random(oracle, hip):
         assert np.array_equal(np.isinf(do), np.isinf(dh))
         fin = np.isfinite(do)
         check(dh[fin], do[fin])
-        # the gradient divides by differences of nearly equal terms in a few degenerate pairs; compare where
-        # the oracle itself is well conditioned and require near-total coverage
-        ok = np.isfinite(go).all(axis=1) & np.isfinite(gh).all(axis=1) & (np.abs(go).max(axis=1) < 1e6)
-        assert ok.mean() > 0.95
+        # The gradient divides by |dist_vec|, L11, L22 and L11 L22 - L12^2 (TaperedCapsuleCollision.cpp:196-258), which vanish on
+        # degenerate pairs (touching capsules, parallel edges).  Conditioning measure, independent of either implementation's
+        # rounding: a pair is well conditioned when the ORACLE's own gradient moves by less than 1e-10 (relative) under a
+        # relative perturbation of 1e-13 of the end points.  On that set the bar is the contract's 1e-9 on every entry; the
+        # excluded fraction is asserted and printed; excluded pairs must still agree on the distance (same branch taken).
+        P2 = P * (1.0 + 1e-13 * np.random.default_rng(F).uniform(-1, 1, P.shape))
+        _, go2 = oracle.capsule_distance_host(P2, dP, R)
+        with np.errstate(invalid="ignore", over="ignore"):
+            sens = np.max(np.abs(go2 - go) / (1 + np.abs(go)), axis=1)
+        finite = np.isfinite(go).all(axis=1) & np.isfinite(go2).all(axis=1)
+        ok = finite & (sens <= 1e-10)
+        assert np.isfinite(gh[ok]).all()
         err = np.abs(gh[ok] - go[ok]) / (1 + np.abs(go[ok]))
-        assert np.quantile(err, 0.999) < 1e-7, np.quantile(err, 0.999)
+        excluded = 1.0 - ok.mean()
+        print(f"capsule gradient F={F}: max err {err.max():.2e} on {ok.sum()} well-conditioned pairs, excluded {100 * excluded:.2f} %")
+        assert err.max() <= TOL, err.max()
+        assert excluded <= 0.005, excluded
+        bad = ~ok & fin
+        check(dh[bad], do[bad])
 
 
 def test_dual_kinova_arm_arm_rows(oracle, hip, kinova):
