@@ -268,6 +268,23 @@ int raptor_eval_batch_host(raptor_problem* problem, const double* Z, int B, unsi
                            double* G, double* JAC);
 
 /*
+ * raptor_eval_batch plus a per-z report of the dependent-joint root finding (SURVEY.md 8b `int* status`).  The reference
+ * runs gsl_multiroot_fdfsolver_hybridsj for at most 50 iterations per time sample and silently accepts whatever it holds at the
+ * end (Examples/Digit/src/DigitDynamicsConstraints.cpp:344-367); so does this library -- the rows of a z whose closed loops
+ * did not close are "what the solver returned" -- but here the caller can see it:
+ *   status[b]     bit RAPTOR_STATUS_NOT_CONVERGED: a closed-loop solve of some sample of z_b ended at the iteration cap with
+ *                 sum|c| >= 1e-14;  bit RAPTOR_STATUS_NONFINITE: one produced a NaN / Inf (singular loop Jacobian);  0: all closed
+ *   iterations[b] (may be NULL) the largest iteration count over the samples and loops of z_b
+ * Problems without a root finder (Kinova, Talos, Unitree-G1: closed forms) report 0 / 0.
+ */
+#define RAPTOR_STATUS_NOT_CONVERGED 1
+#define RAPTOR_STATUS_NONFINITE 2
+int raptor_eval_batch_status(raptor_problem* problem, const double* d_Z, int B, unsigned flags, double* d_G, double* d_JAC,
+                             int* d_status, int* d_iterations, void* hip_stream);
+int raptor_eval_batch_status_host(raptor_problem* problem, const double* Z, int B, unsigned flags, double* G, double* JAC,
+                                  int* status, int* iterations);
+
+/*
  * Component views used by the parity tests, host buffers, synchronous:
  *   Trajectories::compute -> q, q_d, q_dd  [B][N][Nact]   (Trajectories.h:71-76); any may be NULL
  *   InverseDynamics::compute -> tau [B][N][nv], ptau_pz [B][N][nv][n] row-major (InverseDynamics.h:83-85)

@@ -42,6 +42,13 @@ static inline double sign(double val, double eps = 1e-8) {
 // Utils.h:59-68
 static inline double wrapToPi(double angle) {
     double res = angle;
+    // the reference's two loops, bounded like the kernels' (legged_kernel.h wrap_to_pi) so that the checker terminates on the
+    // angles an unclosable z produces: beyond 64 turns one remainder step comes first, a non-finite angle (the reference would
+    // never return) is handed back as it is
+    if (!(std::fabs(res) <= 128.0 * M_PI)) {
+        if (!std::isfinite(res)) return res;
+        res = std::remainder(res, 2.0 * M_PI);
+    }
     while (res > M_PI) res -= 2.0 * M_PI;
     while (res < -M_PI) res += 2.0 * M_PI;
     return res;
@@ -1858,6 +1865,37 @@ int oracle_eval_batch_host(raptor_problem* pr, const double* Z, int B, unsigned 
 }
 int oracle_eval_batch(raptor_problem* pr, const double* Z, int B, unsigned flags, double* G, double* JAC, void*) {
     return oracle_eval_batch_host(pr, Z, B, flags, G, JAC);
+}
+
+// raptor_eval_batch_status: the same evaluation, z by z, with the report of the dependent-joint root finding
+// (DigitDynamicsConstraints.cpp:344-367: at most 50 iterations, the result accepted whatever the solver's state).
+int oracle_eval_batch_status_host(raptor_problem* pr, const double* Z, int B, unsigned flags, double* G, double* JAC, int* status,
+                                  int* iterations) {
+    ORACLE_TRY
+    if (!pr || (B > 0 && (!Z || !status))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    Problem& p = pr->p;
+    for (int b = 0; b < B; b++) {
+        p.dc.stat_flags = 0;
+        p.dc.stat_max_iter = 0;
+        const int rc = oracle_eval_batch_host(pr, Z + (size_t)b * p.n, 1, flags, G ? G + (size_t)b * p.m : nullptr,
+                                              JAC ? JAC + (size_t)b * p.m * p.n : nullptr);
+        if (rc == RAPTOR_ERR_RUNTIME && p.dc.stat_flags != 0) {
+            // a loop Jacobian that is singular at the accepted point: the reference only asserts there
+            // (DigitDynamicsConstraints.cpp:392-393); reported, the rows of this z are left as they are
+            status[b] = p.dc.stat_flags | RAPTOR_STATUS_NONFINITE;
+            if (iterations) iterations[b] = p.dc.stat_max_iter;
+            continue;
+        }
+        if (rc != RAPTOR_OK) return rc;
+        status[b] = p.dc.stat_flags;
+        if (iterations) iterations[b] = p.dc.stat_max_iter;
+    }
+    ORACLE_CATCH
+}
+int oracle_eval_batch_status(raptor_problem* pr, const double* Z, int B, unsigned flags, double* G, double* JAC, int* status,
+                             int* iterations, void*) {
+    return oracle_eval_batch_status_host(pr, Z, B, flags, G, JAC, status, iterations);
 }
 
 // KinovaOptimizer::set_parameters, q_des_input / tplan_n_input (KinovaOptimizer.cpp:28-29, 39-40, 112-113)

@@ -227,8 +227,10 @@ EXPORTS = [
     "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
     "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host", "step_link_eval_batch", "step_link_eval_batch_host",
     "kinova_set_objective", "kinova_eval_objective", "kinova_eval_objective_host", "eval_h_batch", "eval_h_batch_host",
-    "cost_hessian_host",
+    "cost_hessian_host", "eval_batch_status", "eval_batch_status_host",
 ]
+STATUS_NOT_CONVERGED = 1
+STATUS_NONFINITE = 2
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
 DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc"]
 
@@ -275,6 +277,8 @@ class CApi:
         f("eval_h_batch").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
         f("eval_h_batch_host").argtypes = [vp, _dp, C.c_int, _dp, _dp, _dp]
         f("cost_hessian_host").argtypes = [vp, C.c_int, _dp]
+        f("eval_batch_status").argtypes = [vp, vp, C.c_int, C.c_uint, vp, vp, vp, vp, vp]
+        f("eval_batch_status_host").argtypes = [vp, _dp, C.c_int, C.c_uint, _dp, _dp, _ip, _ip]
         if prefix == "oracle_":
             f("inverse_dynamics_hessian_host").argtypes = [vp, _dp, C.c_int, _dp]
         f("profile_begin").argtypes = [vp, C.c_int]
@@ -542,6 +546,17 @@ class ProblemHandle:
         J = np.empty((B, self.m, self.n)) if flags & EVAL_JAC else None
         self.api.check(self.api.fn("eval_batch_host")(self.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J)))
         return G, J
+
+    def eval_status_host(self, Z, flags: int = EVAL_G | EVAL_JAC):
+        """eval_host plus the per-z report of the dependent-joint root finding: (G, JAC, status [B], iterations [B])."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        G = np.empty((B, self.m)) if flags & EVAL_G else None
+        J = np.empty((B, self.m, self.n)) if flags & EVAL_JAC else None
+        st, it = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self.api.check(self.api.fn("eval_batch_status_host")(self.handle, _ptr(Z), B, flags, _ptr(G), _ptr(J),
+                                                              st.ctypes.data_as(_ip), it.ctypes.data_as(_ip)))
+        return G, J, st, it
 
     # -- KinovaOptimizer objective and Optimizer::eval_h -------------------------------------
     def set_objective(self, q_des, tplan_n: int) -> None:

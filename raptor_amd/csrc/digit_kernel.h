@@ -273,7 +273,8 @@ template <bool TOE>
 __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
                                                          const double* __restrict__ basis, const int n,
                                                          const double* __restrict__ Z, const long long total,
-                                                         double* __restrict__ loops) {
+                                                         double* __restrict__ loops, int* __restrict__ status,
+                                                         int* __restrict__ iterations) {
     constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NS = NX * (NX + 1) / 2,
                   NT = NX * (NX + 1) * (NX + 2) / 6;
     const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
     // residual test sum|c| < 1e-14 after a step, at most 50 steps).  Geometry, Jacobian and LU of the accepted point are
     // reused by the derivative phase below.
     int iter = 0;
+    double res_last = 0.0;
 #pragma unroll 1
     while (true) {
         double c[NY];
@@ -340,11 +342,22 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
         double res = 0.0;
 #pragma unroll
         for (int r = 0; r < NY; r++) res += fabs(c[r]);
+        res_last = res;
         if ((iter > 0 && res < 1e-14) || iter >= 50 || !(res == res)) break;  // NaN: singular loop Jacobian, flows to the outputs
         lu_solve<NY>(lu, c);
 #pragma unroll
         for (int r = 0; r < NY; r++) th[r] -= c[r];
         iter++;
+    }
+
+    if (status != nullptr) {
+        // what the reference silently accepts (DigitDynamicsConstraints.cpp:350-367: the GSL loop just ends), made visible per z
+        bool finite = (res_last == res_last);
+#pragma unroll
+        for (int r = 0; r < NY; r++) finite = finite && (fabs(th[r]) <= 1.79e308);
+        const int flag = !finite ? RAPTOR_STATUS_NONFINITE : (!(res_last < 1e-14) ? RAPTOR_STATUS_NOT_CONVERGED : 0);
+        if (flag) atomicOr(status + b, flag);
+        if (iterations != nullptr) atomicMax(iterations + b, iter);
     }
 
     double Y1[NX][NY], U[NX][NY + NX];

@@ -139,6 +139,9 @@ struct raptor_problem {
     bool has_digit = false;
     DevBuf<DevDigit> d_digit;
     DevBuf<double> s_loops;  // per-sample closed-loop records (digit_kernel.h)
+    int* cur_status = nullptr;      // set by raptor_eval_batch_status around one evaluation: per-z report of the loop solves
+    int* cur_iterations = nullptr;
+    DevBuf<int> s_status;           // staging of the *_status_host entry point: status [B] then iterations [B]
     DevBuf<int> d_kinds;
     DevBuf<DevCustRow> d_cust;       // customized block: row specs by row, per-sample row lists
     DevBuf<int> d_cust_list, d_cust_start;
@@ -584,9 +587,9 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
         const long long total = E * 2;
         const unsigned lgrid = (unsigned)((total + 63) / 64);
         hipLaunchKernelGGL((digit_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, total, p.s_loops.p);
+                           p.layout.n, dZ, total, p.s_loops.p, p.cur_status, p.cur_iterations);
         hipLaunchKernelGGL((digit_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, total, p.s_loops.p);
+                           p.layout.n, dZ, total, p.s_loops.p, p.cur_status, p.cur_iterations);
         HIP_CHECK(hipGetLastError());
         d_loops = p.s_loops.p;
     }
@@ -1595,6 +1598,54 @@ int raptor_eval_batch(raptor_problem* p, const double* d_Z, int B, unsigned flag
     API_TRY
     if (!p) throw std::invalid_argument("null problem");
     eval_device(*p, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    API_CATCH
+}
+
+int raptor_eval_batch_status(raptor_problem* p, const double* d_Z, int B, unsigned flags, double* d_G, double* d_JAC, int* d_status,
+                             int* d_iterations, void* stream) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B > 0 && !d_status) throw std::invalid_argument("status buffer is null");
+    if (B == 0) return RAPTOR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)B * sizeof(int), st));
+    if (d_iterations) HIP_CHECK(hipMemsetAsync(d_iterations, 0, (size_t)B * sizeof(int), st));
+    struct Scope {  // the report pointers are valid for this evaluation only
+        raptor_problem* p;
+        ~Scope() { p->cur_status = nullptr; p->cur_iterations = nullptr; }
+    } scope{p};
+    p->cur_status = d_status;
+    p->cur_iterations = d_iterations;
+    eval_device(*p, d_Z, B, flags, d_G, d_JAC, st);
+    API_CATCH
+}
+
+int raptor_eval_batch_status_host(raptor_problem* p, const double* Z, int B, unsigned flags, double* G, double* JAC, int* status,
+                                  int* iterations) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B > 0 && (!Z || !status)) throw std::invalid_argument("null argument");
+    const bool jac = (flags & RAPTOR_EVAL_JAC) != 0, wg = (flags & RAPTOR_EVAL_G) != 0;
+    if (jac && !JAC) throw std::invalid_argument("JAC buffer is null");
+    if (wg && !G) throw std::invalid_argument("G buffer is null");
+    if (B == 0) return RAPTOR_OK;
+    const size_t n = p->layout.n, m = p->layout.m;
+    hipStream_t st = p->hs.stream();
+    p->s_Z.ensure((size_t)B * n);
+    if (wg) p->s_G.ensure((size_t)B * m);
+    if (jac) p->s_J.ensure((size_t)B * m * n);
+    p->s_status.ensure((size_t)2 * B);
+    HIP_CHECK(hipMemcpyAsync(p->s_Z.p, Z, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, st));
+    const int rc = raptor_eval_batch_status(p, p->s_Z.p, B, flags, wg ? p->s_G.p : nullptr, jac ? p->s_J.p : nullptr, p->s_status.p,
+                                            p->s_status.p + B, st);
+    if (rc != RAPTOR_OK) return rc;
+    if (wg) HIP_CHECK(hipMemcpyAsync(G, p->s_G.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (jac) HIP_CHECK(hipMemcpyAsync(JAC, p->s_J.p, (size_t)B * m * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(status, p->s_status.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (iterations) HIP_CHECK(hipMemcpyAsync(iterations, p->s_status.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
     API_CATCH
 }
 

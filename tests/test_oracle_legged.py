@@ -305,3 +305,17 @@ def test_step_link_block_fd(oracle, robot):
         Zn2[0, t * K + 1] = Zn2[0, t * K] + vplus[ind[t]] * cfg.T / cfg.degree
     G2, _, _ = oracle.step_link_host(pc, pn, Zc, Zn2, mp, ni, A.EVAL_G)
     assert np.abs(G2[0, r3]).max() < 1e-12
+
+
+def test_root_finding_status_report(oracle):
+    """oracle_eval_batch_status: closable z report 0 and a handful of Newton steps; joint angles no linkage can follow end at the
+    50-iteration cap and are flagged, as the reference's GSL loop would end (DigitDynamicsConstraints.cpp:344-367)."""
+    keep = []
+    p, _, _ = H.digit_problem(oracle, keep, N=3)
+    rng = np.random.default_rng(0)
+    Z = np.concatenate([0.1 * rng.uniform(-1, 1, (2, p.n)), 3.0 * rng.uniform(-1, 1, (2, p.n))])
+    G, J, st, it = p.eval_status_host(Z)
+    assert list(st[:2]) == [0, 0] and np.all(it[:2] <= 8) and np.all(it[:2] >= 1)
+    assert np.all(st[2:] != 0) and np.all(it[2:] == 50)
+    G2, J2 = p.eval_host(Z[:2])
+    assert np.array_equal(G2, G[:2]) and np.array_equal(J2, J[:2])
