@@ -139,7 +139,7 @@ RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __rest
         V3 o = ow + mul(Rw, v3(J[i].plp[0], J[i].plp[1], J[i].plp[2]));
         double sq, cq;
         const double q = th[digit_chain_var(TOE, CLOSURE, ROD, i)];
-        sincos(q, &sq, &cq);
+        sincos_joint(q, &sq, &cq);
         M3 R;
         SV s;
         joint_world(J[i].jtype, q, cq, sq, A, R, o, s);

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         // ---- phase 0: joint g's trajectory value and sincos ----
         double q, qd, qdd, sq, cq;
         traj_joint(T, basis, z, i, gl, q, qd, qdd);
-        sincos(q, &sq, &cq);
+        sincos_joint(q, &sq, &cq);
         if (own && G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
             G[rowbase + L.off_q + (size_t)i * NV + g] = q;
             G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         // local transform across this joint in the direction of the walk (foot -> this body), so that the walk below is
         // branch free:  forward joint  R' = R (plR Rq),  o' = o + R plp,         axis = R (plR e),   joint origin o'
         //               reversed joint R' = R (plR Rq)^T, o' = o - R' plp,       axis = -R e,        joint origin o
-        sincos(q, &sq, &cq);
+        sincos_joint(q, &sq, &cq);
         M3 P;
 #pragma unroll
         for (int k = 0; k < 9; k++) P.m[k] = M->plR[jnt][k];

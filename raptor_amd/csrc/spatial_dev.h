@@ -71,6 +71,33 @@ RD SV crm(SV v, SV m) { return SV{cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, 
 // motion x* force   (Spatial.h crf)
 RD SV crf(SV v, SV f) { return SV{cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
 
+// sin and cos of a joint angle together.  Joint angles are bounded (|x| < 2^17 here, in practice a few turns), so the argument
+// reduction is three fused multiply-adds against a three-part pi/2 (each product exact inside the fma: the reduced argument is good
+// to ~1.5e-16 absolute up to that bound) followed by the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]
+// (coefficients of the fdlibm k_sin / k_cos kernels, < 1 ulp there).  ~35 VALU instructions against ~170 for the library's
+// full-range sincos; beyond the bound (or non-finite) the library routine is used.
+RD void sincos_joint(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 131072.0)) {
+        sincos(x, sn, cs);
+        return;
+    }
+    const double k = rint(x * 6.36619772367581382433e-01);  // 2 / pi
+    double r = fma(-k, 1.57079632679489655800e+00, x);       // pi / 2, leading 53 bits
+    r = fma(-k, 6.12323399573676603587e-17, r);              // next 53 bits
+    r = fma(-k, -1.49738490485916983327e-33, r);             // and the next
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                         -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                         2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 // rigid-body inertia in world axes: mass, COM position c, rotational inertia about the COM (symmetric)
 struct Inertia {
     double mass;
