@@ -5,7 +5,10 @@
 //   - t_test[8], t_test[9] use the UN-rooted radicand in one term (:131-134);
 //   - for the edge-edge cases 8/9 pu_pz is set with the same expression as pt_pz (:257-258).
 // The per-column gradient terms are independent given the per-pair scalars, so columns are streamed
-// instead of materialising the reference's VecF temporaries.
+// instead of materialising the reference's VecF temporaries.  Two phases per 64-pair wavefront: lane = pair for the 14
+// candidates and the per-pair scalars (left in LDS), then the wave walks the (pair, column) entries of its 64 pairs in flat
+// order -- consecutive lanes read consecutive columns of dP and write consecutive entries of the gradient (with a lane per pair
+// every load touched 64 cache lines 96 F bytes apart: fine at F = 14, eight-fold L2 traffic at F = 112).
 #ifndef RAPTOR_CAPSULE_KERNEL_H
 #define RAPTOR_CAPSULE_KERNEL_H
 
@@ -25,11 +28,16 @@ RD void solve_quadratic_dev(double a, double b, double c, double* s1, double* s2
     *s2 = (-b - sq) / twoa;
 }
 
-__global__ __launch_bounds__(256) void capsule_kernel(const double* __restrict__ P, const double* __restrict__ dP,
-                                                       const double* __restrict__ Rr, const int n_pairs, const int F,
-                                                       double* __restrict__ dist_out, double* __restrict__ grad_out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_pairs) return;
+#define CAPS_BLOCK 64
+#define CAPS_REC 34  // per-pair scalars of the gradient phase, in doubles
+__global__ __launch_bounds__(CAPS_BLOCK) void capsule_kernel(const double* __restrict__ P, const double* __restrict__ dP,
+                                                             const double* __restrict__ Rr, const int n_pairs, const int F,
+                                                             double* __restrict__ dist_out, double* __restrict__ grad_out) {
+    __shared__ double prec[CAPS_BLOCK * CAPS_REC];
+    const int pair0 = blockIdx.x * CAPS_BLOCK;
+    const int idx = pair0 + threadIdx.x;
+    const bool want_grad = dP != nullptr && grad_out != nullptr && F > 0;
+    if (idx < n_pairs) {
     const double* p = P + (size_t)idx * 12;
     const V3 p11 = v3(p[0], p[1], p[2]), p12 = v3(p[3], p[4], p[5]);
     const V3 p21 = v3(p[6], p[7], p[8]), p22 = v3(p[9], p[10], p[11]);
@@ -98,27 +106,48 @@ __global__ __launch_bounds__(256) void capsule_kernel(const double* __restrict__
         }
     }
     dist_out[idx] = best - r11 - r21;
-    if (dP == nullptr || grad_out == nullptr || F <= 0) return;
+    if (want_grad) {
+        // ---- per-pair scalars of the gradient (:162-271) ----
+        const V3 dist_vec = d1 * tStar - d2 * uStar - d12;
+        double purple = sqrt(dot(dist_vec, dist_vec));
+        if (purple == 0) purple = 1e-6;
+        const double orange = a * tStar - b * uStar - c;
+        const double green = -b * tStar - e * uStar + f;
+        const double gradient_factor = 1 / (purple * purple * purple);
+        double* o = prec + threadIdx.x * CAPS_REC;
+        o[0] = d1.x; o[1] = d1.y; o[2] = d1.z; o[3] = d2.x; o[4] = d2.y; o[5] = d2.z; o[6] = d12.x; o[7] = d12.y; o[8] = d12.z;
+        o[9] = tStar; o[10] = uStar; o[11] = purple; o[12] = orange; o[13] = green; o[14] = gradient_factor;
+        o[15] = a / purple - gradient_factor * orange * orange;   // L11
+        o[16] = e / purple - gradient_factor * green * green;     // L22
+        o[17] = -b / purple - gradient_factor * orange * green;   // L12
+        o[18] = r1; o[19] = r2; o[20] = (double)ind;
+    }
+    }
+    if (!want_grad) return;
+    __syncthreads();
 
-    // ---- gradient (:162-271) ----
-    const double* q11 = dP + (size_t)idx * 12 * F;
-    const double* q12 = q11 + 3 * F;
-    const double* q21 = q11 + 6 * F;
-    const double* q22 = q11 + 9 * F;
-    const V3 dist_vec = d1 * tStar - d2 * uStar - d12;
-    double purple = sqrt(dot(dist_vec, dist_vec));
-    if (purple == 0) purple = 1e-6;
-    const double orange = a * tStar - b * uStar - c;
-    const double green = -b * tStar - e * uStar + f;
-    const V3 grey_int = d1 * tStar * tStar - d2 * tStar * uStar - d12 * tStar;
-    const V3 d1md2md12 = d1 - d2 - d12;
-    const V3 hvec = d1 * -tStar + d2 * uStar + d12;
-    const double gradient_factor = 1 / (purple * purple * purple);
-    const double L11 = a / purple - gradient_factor * orange * orange;
-    const double L22 = e / purple - gradient_factor * green * green;
-    const double L12 = -b / purple - gradient_factor * orange * green;
-
-    for (int i = 0; i < F; i++) {
+    // ---- gradient, flat over the (pair, column) entries of this wavefront's pairs ----
+    const int npw = (n_pairs - pair0 < CAPS_BLOCK) ? n_pairs - pair0 : CAPS_BLOCK;
+    const int total = npw * F;
+    const float invF = 1.0f / (float)F;
+    for (int t = threadIdx.x; t < total; t += CAPS_BLOCK) {
+        int pl = (int)(((float)t + 0.5f) * invF);  // t / F: exact here (t < 2^16 F-blocks of at most 64 pairs)
+        if (pl * F > t) pl--;
+        if ((pl + 1) * F <= t) pl++;
+        const int i = t - pl * F;
+        const double* o = prec + pl * CAPS_REC;
+        const V3 d1 = v3(o[0], o[1], o[2]), d2 = v3(o[3], o[4], o[5]), d12 = v3(o[6], o[7], o[8]);
+        const double tStar = o[9], uStar = o[10], purple = o[11], orange = o[12], green = o[13], gradient_factor = o[14];
+        const double L11 = o[15], L22 = o[16], L12 = o[17], r1 = o[18], r2 = o[19];
+        const int ind = (int)o[20];
+        const V3 dist_vec = d1 * tStar - d2 * uStar - d12;
+        const V3 grey_int = d1 * tStar * tStar - d2 * tStar * uStar - d12 * tStar;
+        const V3 d1md2md12 = d1 - d2 - d12;
+        const V3 hvec = d1 * -tStar + d2 * uStar + d12;
+        const double* q11 = dP + (size_t)(pair0 + pl) * 12 * F;
+        const double* q12 = q11 + 3 * F;
+        const double* q21 = q11 + 6 * F;
+        const double* q22 = q11 + 9 * F;
         const V3 pd1 = v3(q12[i] - q11[i], q12[F + i] - q11[F + i], q12[2 * F + i] - q11[2 * F + i]);
         const V3 pd2 = v3(q22[i] - q21[i], q22[F + i] - q21[F + i], q22[2 * F + i] - q21[2 * F + i]);
         const V3 pd12 = v3(q21[i] - q11[i], q21[F + i] - q11[F + i], q21[2 * F + i] - q11[2 * F + i]);
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(256) void capsule_kernel(const double* __restrict__
             pu = (L12 * H2 - L22 * H1) / (L11 * L22 - L12 * L12);
         }
         const V3 colv = pd1 * tStar + d1 * pt - pd2 * uStar - d2 * pu - pd12;
-        grad_out[(size_t)idx * F + i] = dot(dist_vec, colv) / purple - r1 * pt - r2 * pu;
+        grad_out[(size_t)pair0 * F + t] = dot(dist_vec, colv) / purple - r1 * pt - r2 * pu;
     }
 }
 

@@ -2000,7 +2000,7 @@ int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const d
     if (n_pairs == 0) return RAPTOR_OK;
     if (!d_P || !d_R || !d_dist) throw std::invalid_argument("null argument");
     if (d_dP && !d_grad) throw std::invalid_argument("grad buffer is null");
-    hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(n_pairs)), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_P, d_dP,
+    hipLaunchKernelGGL(capsule_kernel, dim3((unsigned)((n_pairs + CAPS_BLOCK - 1) / CAPS_BLOCK)), dim3(CAPS_BLOCK), 0, (hipStream_t)stream, d_P, d_dP,
                        d_R, n_pairs, F, d_dist, d_grad);
     HIP_CHECK(hipGetLastError());
     API_CATCH
@@ -2060,7 +2060,7 @@ static void dual_arm_arm_device(raptor_problem& p1, raptor_problem& p2, const do
         hipLaunchKernelGGL(dual_kinova_points_kernel, dim3((np + 63) / 64), dim3(64), 0, st, p1.d_model.p, p1.d_traj.p, p1.d_basis.p,
                            p1.d_wsum.p, p1.d_spheres.p, p2.d_model.p, p2.d_traj.p, p2.d_basis.p, p2.d_wsum.p, p2.d_spheres.p, caps, dZ,
                            p0, np, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR);
-        hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(np)), dim3(RAPTOR_BLOCK), 0, st, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR, np, F,
+        hipLaunchKernelGGL(capsule_kernel, dim3((unsigned)((np + CAPS_BLOCK - 1) / CAPS_BLOCK)), dim3(CAPS_BLOCK), 0, st, p1.s_a.p, jac ? p1.s_b.p : nullptr, dR, np, F,
                            (flags & RAPTOR_EVAL_G) ? dG + p0 : dDist, jac ? dJ + (size_t)p0 * F : nullptr);
         HIP_CHECK(hipGetLastError());
     }
@@ -2148,7 +2148,7 @@ int raptor_capsule_distance_batch_host(const double* P, const double* dP, const 
         bdP.upload(dP, (size_t)n_pairs * 12 * F);
         bg.ensure((size_t)n_pairs * std::max(F, 1));
     }
-    hipLaunchKernelGGL(capsule_kernel, dim3(grid_for(n_pairs)), dim3(RAPTOR_BLOCK), 0, nullptr, bP.p, dP ? bdP.p : nullptr,
+    hipLaunchKernelGGL(capsule_kernel, dim3((unsigned)((n_pairs + CAPS_BLOCK - 1) / CAPS_BLOCK)), dim3(CAPS_BLOCK), 0, nullptr, bP.p, dP ? bdP.p : nullptr,
                        bR.p, n_pairs, F, bd.p, dP ? bg.p : nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
