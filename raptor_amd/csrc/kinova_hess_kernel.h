@@ -29,6 +29,8 @@
 #ifndef RAPTOR_KINOVA_HESS_KERNEL_H
 #define RAPTOR_KINOVA_HESS_KERNEL_H
 
+#include <type_traits>
+
 #include "kinova_kernel.h"
 #include "legged_kernel.h"  // wrap_to_pi
 
@@ -41,8 +43,12 @@
 #define HL_WS (HL_MU + 7 * H_CH)      // pq_pz, pq_d_pz, pq_dd_pz diagonal            3 x 64
 #define HL_W (HL_WS + 3 * H_CH)       // per joint: world axis (3), world origin (3)  42 x 64
 #define HL_RO (HL_W + 42 * H_CH)      // R, o of up to 4 sphere-carrying links        48 x 64
-#define HL_ACC (HL_RO + 48 * H_CH)    // per wavefront: 28 obstacle partial sums, then 28 torque sums
+// the torque phase keeps each wavefront's hyper-dual virtual velocity (wa, wl: 6 x 4 doubles per sample) in LDS, [field][64],
+// on top of the obstacle tables HL_W / HL_RO (filled after the torque phase): 4 x 24 = 96 fields over 90 + 6
+#define HL_WST HL_W
+#define HL_ACC (HL_W + H_WAVES * 24 * H_CH)  // per wavefront: 28 obstacle partial sums, then 28 torque sums
 #define HL_TOTAL (HL_ACC + 2 * H_WAVES * H_PAIRS)
+static_assert(HL_RO + 48 * H_CH <= HL_ACC, "obstacle tables fit under the w state");
 
 // first-order dual and hyper-dual numbers
 struct D1 {
@@ -124,14 +130,35 @@ RD Kin<S> promote(const Kin<P>& k) {
     return r;
 }
 
+template <class S>
+RD T3<S> mulM(const double (&A)[9], const T3<S>& x) {  // A x, row-major A
+    return T3<S>{{A[0] * x.c[0] + A[1] * x.c[1] + A[2] * x.c[2], A[3] * x.c[0] + A[4] * x.c[1] + A[5] * x.c[2],
+                  A[6] * x.c[0] + A[7] * x.c[1] + A[8] * x.c[2]}};
+}
+// Past the seeded links the joint's sine / cosine are plain numbers: rotation about local axis K after the fixed placement
+// is ONE matrix per (sample, link), Et = Rot_K(theta)^T plR^T, applied to every motion vector (36 instead of 52 multiply-adds
+// per hyper-dual vector).
+template <int K>
+RD void make_Et(const double* R, double C, double Sn, double (&Et)[9]) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        Et[I * 3 + c] = C * R[c * 3 + I] + Sn * R[c * 3 + J];
+        Et[J * 3 + c] = C * R[c * 3 + J] - Sn * R[c * 3 + I];
+        Et[K * 3 + c] = R[c * 3 + K];
+    }
+}
+RD void make_Et(const double* R, int aj, double C, double Sn, double (&Et)[9]) {
+    if (aj == 3) make_Et<2>(R, C, Sn, Et);
+    else if (aj == 2) make_Et<1>(R, C, Sn, Et);
+    else make_Et<0>(R, C, Sn, Et);
+}
+
 // Joint about local axis K (Spatial.h:115-258 jcalc, Xup = XJ * Xtree): rotate the parent's motion vectors into the link
 // frame, add the joint's own motion S = sg e_K.  C = cos(theta), Sn = sin(theta), theta = sg q; Tq = double past the seeded link.
 template <int K, class S, class Tq>
-RD void hess_joint(Tq C, Tq Sn, double sg, Tq qd, Tq qdd, double mu, Kin<S>& k) {
+RD void hess_motion(double sg, Tq qd, Tq qdd, double mu, Kin<S>& k) {
     constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
-#define HROT(x) { const S xi_ = C * x.c[I] + Sn * x.c[J]; const S xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
-    HROT(k.va) HROT(k.vl) HROT(k.aa) HROT(k.al) HROT(k.wa) HROT(k.wl)
-#undef HROT
     const Tq vj = sg * qd;
     k.va.c[K] = k.va.c[K] + vj;  // v_l = Xup v_parent + S q_d                 (CustomizedInverseDynamics.cpp:155)
     // a_l = Xup a_parent + crm(v_l) (S q_d) + S q_dd                            (:157)
@@ -142,26 +169,169 @@ RD void hess_joint(Tq C, Tq Sn, double sg, Tq qd, Tq qdd, double mu, Kin<S>& k) 
     k.aa.c[K] = k.aa.c[K] + sg * qdd;
     add_value(k.wa.c[K], sg * mu);  // virtual velocity under joint rates mu
 }
+template <int K, class S, class Tq>
+RD void hess_joint(Tq C, Tq Sn, double sg, Tq qd, Tq qdd, double mu, Kin<S>& k) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+#define HROT(x) { const S xi_ = C * x.c[I] + Sn * x.c[J]; const S xj_ = C * x.c[J] - Sn * x.c[I]; x.c[I] = xi_; x.c[J] = xj_; }
+    HROT(k.va) HROT(k.vl) HROT(k.aa) HROT(k.al) HROT(k.wa) HROT(k.wl)
+#undef HROT
+    hess_motion<K>(sg, qd, qdd, mu, k);
+}
 template <class S, class Tq>
 RD void hess_link(const DevModel* __restrict__ M, int l, Tq C, Tq Sn, Tq qd, Tq qdd, double mu, Kin<S>& k) {
     // Xtree = plux(R^T, p): [w; v] -> [R^T w; R^T (v + w x p)]   (CustomizedInverseDynamics.cpp:43-47, Utils.h:185-191)
     const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
-    k.vl = mulT(M->plR[l], k.vl + cross(k.va, p));
-    k.va = mulT(M->plR[l], k.va);
-
-    k.al = mulT(M->plR[l], k.al + cross(k.aa, p));
-    k.aa = mulT(M->plR[l], k.aa);
-
-    k.wl = mulT(M->plR[l], k.wl + cross(k.wa, p));
-    k.wa = mulT(M->plR[l], k.wa);
-
     const int jt = M->jtype[l];
     const double sg = jt < 0 ? -1.0 : 1.0;
     const int aj = jt < 0 ? -jt : jt;
-    if (aj == 3) hess_joint<2>(C, Sn, sg, qd, qdd, mu, k);
-    else if (aj == 2) hess_joint<1>(C, Sn, sg, qd, qdd, mu, k);
-    else hess_joint<0>(C, Sn, sg, qd, qdd, mu, k);
+    if constexpr (std::is_same<Tq, double>::value) {  // past the seeded links: placement and rotation as one matrix
+        double Et[9];
+        make_Et(M->plR[l], aj, C, Sn, Et);
+        k.vl = mulM(Et, k.vl + cross(k.va, p));
+        k.va = mulM(Et, k.va);
+        k.al = mulM(Et, k.al + cross(k.aa, p));
+        k.aa = mulM(Et, k.aa);
+        k.wl = mulM(Et, k.wl + cross(k.wa, p));
+        k.wa = mulM(Et, k.wa);
+        if (aj == 3) hess_motion<2>(sg, qd, qdd, mu, k);
+        else if (aj == 2) hess_motion<1>(sg, qd, qdd, mu, k);
+        else hess_motion<0>(sg, qd, qdd, mu, k);
+    } else {
+        k.vl = mulT(M->plR[l], k.vl + cross(k.va, p));
+        k.va = mulT(M->plR[l], k.va);
+
+        k.al = mulT(M->plR[l], k.al + cross(k.aa, p));
+        k.aa = mulT(M->plR[l], k.aa);
+
+        k.wl = mulT(M->plR[l], k.wl + cross(k.wa, p));
+        k.wa = mulT(M->plR[l], k.wa);
+
+        if (aj == 3) hess_joint<2>(C, Sn, sg, qd, qdd, mu, k);
+        else if (aj == 2) hess_joint<1>(C, Sn, sg, qd, qdd, mu, k);
+        else hess_joint<0>(C, Sn, sg, qd, qdd, mu, k);
+    }
 }
+// The hyper-dual regime keeps v, a in registers and the virtual velocity w in LDS (`ws`: this lane's column of the wavefront's
+// [24][64] area: field = (vector * 3 + component) * 4 + part): 72 hyper-dual doubles do not fit 256 registers with the force
+// temporaries beside them, and two wavefronts per SIMD need that.
+RD T3<HD> w_load(const double* ws, int vec) {
+    T3<HD> x;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double* f = ws + ((vec * 3 + i) * 4) * H_CH;
+        x.c[i] = HD{f[0], f[H_CH], f[2 * H_CH], f[3 * H_CH]};
+    }
+    return x;
+}
+RD void w_store(double* ws, int vec, const T3<HD>& x) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double* f = ws + ((vec * 3 + i) * 4) * H_CH;
+        f[0] = x.c[i].v; f[H_CH] = x.c[i].a; f[2 * H_CH] = x.c[i].b; f[3 * H_CH] = x.c[i].ab;
+    }
+}
+template <class S>
+struct KinVA {
+    T3<S> va, vl, aa, al;
+};
+template <int K, class X>
+RD void hess_rot(const HD C, const HD Sn, X& x) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+    const HD xi_ = C * x.c[I] + Sn * x.c[J];
+    const HD xj_ = C * x.c[J] - Sn * x.c[I];
+    x.c[I] = xi_;
+    x.c[J] = xj_;
+}
+template <int K, class Tq>
+RD void hess_motion_va(double sg, Tq qd, Tq qdd, KinVA<HD>& k) {  // the joint's own motion, after the rotation (:155-157)
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+    const Tq vj = sg * qd;
+    k.va.c[K] = k.va.c[K] + vj;
+    k.aa.c[I] = k.aa.c[I] + k.va.c[J] * vj;
+    k.aa.c[J] = k.aa.c[J] - k.va.c[I] * vj;
+    k.al.c[I] = k.al.c[I] + k.vl.c[J] * vj;
+    k.al.c[J] = k.al.c[J] - k.vl.c[I] * vj;
+    k.aa.c[K] = k.aa.c[K] + sg * qdd;
+}
+// one link of the hyper-dual regime: w in LDS first (its registers are free again before the forces are formed), then v, a
+RD void hess_link_hd(const DevModel* __restrict__ M, int l, double C, double Sn, double qd, double qdd, double mu, KinVA<HD>& k,
+          double* ws) {
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    double Et[9];
+    make_Et(M->plR[l], aj, C, Sn, Et);
+    {
+        T3<HD> wa = w_load(ws, 0), wl = w_load(ws, 1);
+        wl = mulM(Et, wl + cross(wa, p));
+        wa = mulM(Et, wa);
+        if (aj == 3) add_value(wa.c[2], sg * mu);
+        else if (aj == 2) add_value(wa.c[1], sg * mu);
+        else add_value(wa.c[0], sg * mu);
+        w_store(ws, 0, wa);
+        w_store(ws, 1, wl);
+    }
+    asm volatile("" ::: "memory");  // the forces below read w back from LDS: no forwarding of the 24 values through registers
+    k.vl = mulM(Et, k.vl + cross(k.va, p));
+    k.va = mulM(Et, k.va);
+    k.al = mulM(Et, k.al + cross(k.aa, p));
+    k.aa = mulM(Et, k.aa);
+    if (aj == 3) hess_motion_va<2>(sg, qd, qdd, k);
+    else if (aj == 2) hess_motion_va<1>(sg, qd, qdd, k);
+    else hess_motion_va<0>(sg, qd, qdd, k);
+}
+// the seeded link: sine / cosine carry derivative parts, placement and rotation stay two steps
+RD void hess_link_hd(const DevModel* __restrict__ M, int l, HD C, HD Sn, HD qd, HD qdd, double mu, KinVA<HD>& k, double* ws) {
+    const V3 p = v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]);
+    const int jt = M->jtype[l];
+    const double sg = jt < 0 ? -1.0 : 1.0;
+    const int aj = jt < 0 ? -jt : jt;
+    {
+        T3<HD> wa = w_load(ws, 0), wl = w_load(ws, 1);
+        wl = mulT(M->plR[l], wl + cross(wa, p));
+        wa = mulT(M->plR[l], wa);
+        if (aj == 3) { hess_rot<2>(C, Sn, wa); hess_rot<2>(C, Sn, wl); add_value(wa.c[2], sg * mu); }
+        else if (aj == 2) { hess_rot<1>(C, Sn, wa); hess_rot<1>(C, Sn, wl); add_value(wa.c[1], sg * mu); }
+        else { hess_rot<0>(C, Sn, wa); hess_rot<0>(C, Sn, wl); add_value(wa.c[0], sg * mu); }
+        w_store(ws, 0, wa);
+        w_store(ws, 1, wl);
+    }
+    asm volatile("" ::: "memory");
+    k.vl = mulT(M->plR[l], k.vl + cross(k.va, p));
+    k.va = mulT(M->plR[l], k.va);
+    k.al = mulT(M->plR[l], k.al + cross(k.aa, p));
+    k.aa = mulT(M->plR[l], k.aa);
+    if (aj == 3) { hess_rot<2>(C, Sn, k.va); hess_rot<2>(C, Sn, k.vl); hess_rot<2>(C, Sn, k.aa); hess_rot<2>(C, Sn, k.al); hess_motion_va<2>(sg, qd, qdd, k); }
+    else if (aj == 2) { hess_rot<1>(C, Sn, k.va); hess_rot<1>(C, Sn, k.vl); hess_rot<1>(C, Sn, k.aa); hess_rot<1>(C, Sn, k.al); hess_motion_va<1>(sg, qd, qdd, k); }
+    else { hess_rot<0>(C, Sn, k.va); hess_rot<0>(C, Sn, k.vl); hess_rot<0>(C, Sn, k.aa); hess_rot<0>(C, Sn, k.al); hess_motion_va<0>(sg, qd, qdd, k); }
+}
+RD double dot_ab_lds(const double* ws, int vec, const T3<HD>& y) {  // the mixed part of w . y, w read from LDS
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double* f = ws + ((vec * 3 + i) * 4) * H_CH;
+        s += f[0] * y.c[i].ab + f[H_CH] * y.c[i].b + f[2 * H_CH] * y.c[i].a + f[3 * H_CH] * y.c[i].v;
+    }
+    return s;
+}
+RD double hess_power_ab_lds(const DevModel* __restrict__ M, int l, const KinVA<HD>& k, const double* ws) {
+    const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
+    const double mass = M->mass[l];
+    T3<HD> hl = k.vl + cross(k.va, c);  // momentum, linear part
+    T3<HD> gl = k.al + cross(k.aa, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        hl.c[i] = mass * hl.c[i];
+        gl.c[i] = mass * gl.c[i];
+    }
+    const T3<HD> fl = gl + cross(k.va, hl);
+    double s = dot_ab_lds(ws, 1, fl);
+    const T3<HD> ha = symmul(M->Ic[l], k.va) + cross(c, hl);
+    const T3<HD> fa = symmul(M->Ic[l], k.aa) + cross(c, gl) + cross(k.va, ha) + cross(k.vl, hl);
+    return s + dot_ab_lds(ws, 0, fa);
+}
+
 // mixed part of w . f,  f = I a + v x* (I v),  I = (mass, lever, inertia about the COM) in the link frame (:244-246)
 RD double hess_power_ab(const DevModel* __restrict__ M, int l, const Kin<HD>& k) {
     const V3 c = v3(M->lever[l][0], M->lever[l][1], M->lever[l][2]);
@@ -399,8 +569,11 @@ RD int pair_index(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a); } 
 // (blockIdx.y = slot): each wavefront takes ONE pair and every 28th sphere, the 28 partial sums go to `Hout` =
 // part[B][7][28] and kinova_hessian_reduce_kernel adds them in a fixed order -- the single-problem (Ipopt-driven) case,
 // where one workgroup per z would leave the chip idle.
+#ifndef H_OCC
+#define H_OCC 2  // waves per SIMD the register allocation must leave room for (w state in LDS: 252 VGPRs, no AGPR copies)
+#endif
 template <bool SPLIT>
-__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
+__global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
     const double* __restrict__ Z, const double* __restrict__ obj_factor, const double* __restrict__ lambda, const int tplan_n,
@@ -439,6 +612,68 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
         const bool live = (i0 + lane) < N;
         const double w0 = lds[HL_WS + lane], w1 = lds[HL_WS + H_CH + lane], w2 = lds[HL_WS + 2 * H_CH + lane];
 
+        // ---- torque rows: this wavefront's seven pairs, lane = sample ----
+#pragma unroll 1
+        for (int it = SPLIT ? (int)blockIdx.y : 0; it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
+            const int code = H_PAIR_OF[wave][it];
+            const int pa = code >> 3, pb = code & 7;
+            Kin<double> k0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
+                k0.al.c[k] = M->neg_gravity[k];  // base acceleration -a_grav (CustomizedInverseDynamics.cpp:212)
+            }
+#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
+#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
+            int l = 0;
+#pragma unroll 1
+            for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
+            KinVA<HD> kh;
+            double* ws = lds + HL_WST + wave * 24 * H_CH + lane;  // this lane's column of the wavefront's w state
+#define HPROM(src) \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { \
+        kh.va.c[i_] = promote(src.va.c[i_], (HD*)nullptr); kh.vl.c[i_] = promote(src.vl.c[i_], (HD*)nullptr); \
+        kh.aa.c[i_] = promote(src.aa.c[i_], (HD*)nullptr); kh.al.c[i_] = promote(src.al.c[i_], (HD*)nullptr); \
+    } \
+    { T3<HD> wa_, wl_; \
+      _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { wa_.c[i_] = promote(src.wa.c[i_], (HD*)nullptr); wl_.c[i_] = promote(src.wl.c[i_], (HD*)nullptr); } \
+      w_store(ws, 0, wa_); w_store(ws, 1, wl_); }
+            if (pa < pb) {
+                Kin<D1> k1 = promote<D1>(k0);
+                {   // l == pa: seeded in z_a
+                    const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                    hess_link(M, l, D1{cq, -sq * w0}, sg * D1{sq, cq * w0}, D1{HX(l, 0), w1}, D1{HX(l, 1), w2},
+                              lds[HL_MU + l * H_CH + lane], k1);
+                    l++;
+                }
+#pragma unroll 1
+                for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1);
+                HPROM(k1)
+            } else {
+                HPROM(k0)
+            }
+#undef HPROM
+            double phi_ab;
+            {   // l == pb: seeded in z_b (and in z_a on the diagonal)
+                const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
+                const double da = (pa == pb) ? w0 : 0.0, ea = (pa == pb) ? w1 : 0.0, fa = (pa == pb) ? w2 : 0.0;
+                hess_link_hd(M, l, HD{cq, -sq * da, -sq * w0, -cq * da * w0}, sg * HD{sq, cq * da, cq * w0, -sq * da * w0},
+                             HD{HX(l, 0), ea, w1, 0.0}, HD{HX(l, 1), fa, w2, 0.0}, lds[HL_MU + l * H_CH + lane], kh, ws);
+                phi_ab = hess_power_ab_lds(M, l, kh, ws);
+                l++;
+            }
+#pragma unroll 1
+            for (; l < NV; l++) {
+                hess_link_hd(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh, ws);
+                phi_ab += hess_power_ab_lds(M, l, kh, ws);
+            }
+#undef HX
+#undef HSG
+            const double tot = wave_sum(live ? phi_ab : 0.0);
+            if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + H_PAIRS + pair_index(pa, pb)] += tot;
+        }
+        __syncthreads();  // every wavefront is done with its w state: the obstacle tables take the same LDS
+
         // ---- world-frame joint axes / origins and sphere-link poses of every sample (first wavefront, lane = sample) ----
         if (wave == 0 && O > 0) {
             M3 Rw;
@@ -468,56 +703,6 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hessian_kernel(
             }
         }
 
-        // ---- torque rows: this wavefront's seven pairs, lane = sample ----
-#pragma unroll 1
-        for (int it = SPLIT ? (int)blockIdx.y : 0; it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
-            const int code = H_PAIR_OF[wave][it];
-            const int pa = code >> 3, pb = code & 7;
-            Kin<double> k0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
-                k0.al.c[k] = M->neg_gravity[k];  // base acceleration -a_grav (CustomizedInverseDynamics.cpp:212)
-            }
-#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
-#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
-            int l = 0;
-#pragma unroll 1
-            for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
-            Kin<HD> kh;
-            if (pa < pb) {
-                Kin<D1> k1 = promote<D1>(k0);
-                {   // l == pa: seeded in z_a
-                    const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
-                    hess_link(M, l, D1{cq, -sq * w0}, sg * D1{sq, cq * w0}, D1{HX(l, 0), w1}, D1{HX(l, 1), w2},
-                              lds[HL_MU + l * H_CH + lane], k1);
-                    l++;
-                }
-#pragma unroll 1
-                for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1);
-                kh = promote<HD>(k1);
-            } else {
-                kh = promote<HD>(k0);
-            }
-            double phi_ab;
-            {   // l == pb: seeded in z_b (and in z_a on the diagonal)
-                const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
-                const double da = (pa == pb) ? w0 : 0.0, ea = (pa == pb) ? w1 : 0.0, fa = (pa == pb) ? w2 : 0.0;
-                hess_link(M, l, HD{cq, -sq * da, -sq * w0, -cq * da * w0}, sg * HD{sq, cq * da, cq * w0, -sq * da * w0},
-                          HD{HX(l, 0), ea, w1, 0.0}, HD{HX(l, 1), fa, w2, 0.0}, lds[HL_MU + l * H_CH + lane], kh);
-                phi_ab = hess_power_ab(M, l, kh);
-                l++;
-            }
-#pragma unroll 1
-            for (; l < NV; l++) {
-                hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh);
-                phi_ab += hess_power_ab(M, l, kh);
-            }
-#undef HX
-#undef HSG
-            const double tot = wave_sum(live ? phi_ab : 0.0);
-            if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + H_PAIRS + pair_index(pa, pb)] += tot;
-        }
         __syncthreads();  // world-frame tables complete
 
         // ---- obstacle rows: a wavefront per sphere, lane = sample ----
