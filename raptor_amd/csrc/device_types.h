@@ -95,6 +95,11 @@ struct DevLegged {
     int col_nsupp[RAPTOR_LEG_MAX_IND];        // tree joints that move with independent joint t ...
     int col_supp_body[RAPTOR_LEG_MAX_IND][8]; // ... their bodies ...
     int col_supp_slot[RAPTOR_LEG_MAX_IND][8]; // ... and which of their weight slots points at t
+    // the same tables packed for the core kernel, which reads them once into registers instead of chasing them through
+    // dependent loads inside its loops: an entry is  body | end(body) << 5 | slot << 11 | flag << 12 | column << 13
+    unsigned long long path8[RAPTOR_LEG_MAX_BODIES][3];     // path[g][0 .. depth-1], one byte each
+    unsigned long long col_pack[RAPTOR_LEG_MAX_IND][2];     // col_supp_*[t][0..7], 16 bits each, flag = entry valid
+    int flat_n, flat[64];                                   // all (column, support joint) pairs in column order, flag = last of its column
     int ind_ndep[RAPTOR_LEG_MAX_IND];         // dependent loop joints of independent joint t
     int ind_dep_body[RAPTOR_LEG_MAX_IND][6];
     int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int tid = threadIdx.x;
     const int g = tid & (LG - 1);
     const int eg = tid / LG;
-    const long long e = (long long)blockIdx.x * EPB + eg;
-    if (e >= E) return;  // whole lane groups leave together
+    // a lane group past the end repeats the last sample-eval (same values to the same addresses): every lane of the wavefront
+    // stays active, which the packed table of phase F2 (an entry per lane, read with v_readlane) relies on
+    const long long e = min((long long)blockIdx.x * EPB + eg, E - 1);
     double* sl = lds + eg * LL::STRIDE;
     const int N = T->N;
     const int i = (int)(e % N);
@@ -142,6 +143,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int rc = has_joint ? Q->body_rec[gb] : -1;
     const int gend = has_body ? Q->body_end[gb] : LG;
     const double* lr = (rc >= 0) ? loops + ((size_t)e * Q->nrec + rc) * 10 : nullptr;
+    // tables this lane walks later, fetched now: inside the loops a dependent global load per step is what the two wavefronts
+    // per SIMD cannot hide
+    unsigned long long pcur = Q->path8[gb][0];
+    const unsigned long long pnext1 = Q->path8[gb][1], pnext2 = Q->path8[gb][2];
+    const double arm_j = has_joint ? M->armature[jnt] : 0.0, damp_j = has_joint ? M->damping[jnt] : 0.0;
 
     // ---- phase 0: this body's joint value, rates, chain-rule weights towards the independent columns, sincos ----
     double q = 0.0, qd = 0.0, qdd = 0.0, sq = 0.0, cq = 1.0;
@@ -211,7 +217,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int depth = has_body ? Q->body_depth[gb] : 0;
 #pragma unroll 1
     for (int d = 0; d < depth; d++) {
-        const double* x = sl + LL::V + Q->path[gb][d] * LEG_LOC;
+        const double* x = sl + LL::V + (int)(pcur & 255ull) * LEG_LOC;
+        pcur >>= 8;
+        if (d == 7) pcur = pnext1;
+        if (d == 15) pcur = pnext2;
         const M3 R = mul(Rw, x);
         const V3 o = ow + mul(Rw, v3(x[9], x[10], x[11]));
         const V3 axw = mul(Rw, v3(x[12], x[13], x[14]));
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
     // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
-    const double tt = has_joint ? dot(s, F) + M->armature[jnt] * qdd + M->damping[jnt] * qd : 0.0;
+    const double tt = has_joint ? dot(s, F) + arm_j * qdd + damp_j * qd : 0.0;
     if (has_joint) {
         rec[Q->c_q + jnt] = q;
         rec[Q->c_v + jnt] = qd;
@@ -311,9 +320,12 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int myslot = (tj >= 0) ? Q->ind_slot[tj] : 0;
     const int ndep = (tj >= 0) ? Q->ind_ndep[tj] : 0;
     double gdep[6], tdep[6];
+    int depb[6];  // bodies of the closed-loop joints this actuator drives
+#pragma unroll
+    for (int d = 0; d < 6; d++) depb[d] = (d < ndep) ? Q->ind_dep_body[tj][d] : 0;
 #pragma unroll
     for (int d = 0; d < 6; d++) {
-        const int db = (d < ndep) ? Q->ind_dep_body[tj][d] : 0;
+        const int db = depb[d];
         const double ga = __shfl(w0[0], db, LG), gb_ = __shfl(w1[0], db, LG);
         const double td = __shfl(tt, db, LG);
         gdep[d] = (d < ndep) ? (myslot ? gb_ : ga) : 0.0;
@@ -398,24 +410,27 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
             for (int k = 0; k < 6; k++) X[6 + k] = __shfl(mine[k], Q->torso_body, LG);
         }
+        {
+            const double mine[6] = {psf.x, psf.y, psf.z, rpy.x, rpy.y, rpy.z};
+#pragma unroll
+            for (int k = 0; k < 6; k++) X[k] = __shfl(mine[k], Q->sf_body, LG);
+        }
         if (is_sf) {
-            X[0] = psf.x; X[1] = psf.y; X[2] = psf.z;
-            X[3] = rpy.x; X[4] = rpy.y; X[5] = rpy.z;
 #pragma unroll
             for (int k = 0; k < 6; k++) rec[Q->c_sf + k] = X[k];
-            if (G != nullptr) {
-                for (int rr = cust_start[i]; rr < cust_start[i + 1]; rr++) {
-                    const int row = cust_list[rr];
-                    const DevCustRow cr = cust[row];
-                    double xa = 0.0, xb = 0.0;
+        }
+        if (G != nullptr) {  // this sample's rows, one per lane and round: the table look-ups of a row are a chain of dependent loads
+            for (int rr = cust_start[i] + g; rr < cust_start[i + 1]; rr += LG) {
+                const int row = cust_list[rr];
+                const DevCustRow cr = cust[row];
+                double xa = 0.0, xb = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 12; k++) {
-                        xa = (k == cr.qa) ? X[k] : xa;
-                        xb = (k == cr.qb) ? X[k] : xb;
-                    }
-                    const double val = cr.ca * xa + cr.cb * xb + cr.add;
-                    G[rowbase + Q->off_cust + row] = cr.wrap ? wrap_to_pi(val) : val;
+                for (int k = 0; k < 12; k++) {
+                    xa = (k == cr.qa) ? X[k] : xa;
+                    xb = (k == cr.qb) ? X[k] : xb;
                 }
+                const double val = cr.ca * xa + cr.cb * xb + cr.add;
+                G[rowbase + Q->off_cust + row] = cr.wrap ? wrap_to_pi(val) : val;
             }
         }
     }
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
     for (int d = 0; d < 6; d++) {
         if (d < ndep) {
-            const int db = Q->ind_dep_body[tj][d];
+            const int db = depb[d];
             const double* ld = loops + ((size_t)e * Q->nrec + Q->body_rec[db]) * 10;
             Kq[0] += ld[3 + myslot] * tdep[d];
             Kq[1] += ld[4 + myslot] * tdep[d];
@@ -477,13 +492,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         const V3 ps = v3(__shfl(psf.x, sb, LG), __shfl(psf.y, sb, LG), __shfl(psf.z, sb, LG));
         const bool col = g < ni;
         const int t = col ? g : 0;
-        const int ns = col ? Q->col_nsupp[t] : 0;
+        unsigned long long cp = col ? Q->col_pack[t][0] : 0ull;
+        const unsigned long long cp1 = col ? Q->col_pack[t][1] : 0ull;
         SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), twt = sv_zero(), tws = sv_zero();
 #pragma unroll 1
         for (int r = 0; r < 8; r++) {
-            const bool on = r < ns;
-            const int k = on ? Q->col_supp_body[t][r] : 1;
-            const bool s1 = on && Q->col_supp_slot[t][r] != 0;
+            const unsigned ent = (unsigned)cp & 0xffffu;
+            cp >>= 16;
+            if (r == 3) cp = cp1;
+            const bool on = (ent >> 12 & 1u) != 0;
+            const int k = on ? (int)(ent & 31u) : 1;
+            const bool s1 = (ent >> 11 & 1u) != 0;
             const double a0 = __shfl(w0[0], k, LG), a1 = __shfl(w0[1], k, LG), a2 = __shfl(w0[2], k, LG);
             const double b0 = __shfl(w1[0], k, LG), b1 = __shfl(w1[1], k, LG), b2 = __shfl(w1[2], k, LG);
             if (on) {
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 Fa = Fa + ISk * g0;
                 Fv = Fv + cvk * g0 + ISk * hv;
                 Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
-                const int kend = Q->body_end[k];
+                const int kend = (int)(ent >> 5 & 63u);
                 if (tb >= k && tb < kend) twt = twt + sk * g0;
                 if (Q->ncust > 0 && sb >= k && sb < kend) tws = tws + sk * g0;
             }
@@ -534,14 +553,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // k and (IS_j; s_k, sd_k, psi_k) when k is j or an ancestor of j,
     //     M_jk = A.U1,   dtau_j/dv_k = f A.U2 + BtS_j.U1,   dtau_j/dq_k = A.U3 + BtS_j.U2     (f = 1 / 2, BtS terms only in
     // the second case); both vector triples sit 18 doubles apart in the LDS slots, so the choice is an address offset.
+    // The (column, joint) pairs come from one packed table, a lane each, read with v_readlane: no memory access decides
+    // what the next step works on.
+    const int flat = Q->flat[tid];
+    const int nflat = Q->flat_n;
+    double Tq = 0.0, Tv = 0.0, Ta = 0.0;
 #pragma unroll 1
-    for (int it = 0; it < ni; it++) {
-        const int ns = Q->col_nsupp[it];
-        double Tq = 0.0, Tv = 0.0, Ta = 0.0;
-        for (int r = 0; r < ns; r++) {
-            const int k = Q->col_supp_body[it][r];
-            const int kend = Q->body_end[k];
-            const bool s1 = Q->col_supp_slot[it][r] != 0;  // uniform
+    for (int idx = 0; idx < nflat; idx++) {
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane(flat, idx);
+        const int k = (int)(ent & 31u), kend = (int)(ent >> 5 & 63u);
+        const bool s1 = (ent >> 11 & 1u) != 0;  // uniform
+        {
             const double g0 = __shfl(s1 ? w1[0] : w0[0], k, LG), hv = __shfl(s1 ? w1[1] : w0[1], k, LG),
                          hq = __shfl(s1 ? w1[2] : w0[2], k, LG);
             const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
@@ -554,16 +576,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const double e2 = dot(BtS, U1), e3 = dot(BtS, U2);
             double dv = anc ? t2 : 2.0 * t2 + e2;
             double dq = anc ? t3 : t3 + e3;
-            if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
-                da += M->armature[jnt];
-                dv += M->damping[jnt];
-            }
+            const double own = (g == k) ? 1.0 : 0.0;  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
+            da += own * arm_j;
+            dv += own * damp_j;
             const double rel = (anc || dsc) ? 1.0 : 0.0;
             da *= rel; dv *= rel; dq *= rel;
             Ta += da * g0;
             Tv += dv * g0 + da * hv;
             Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
         }
+        if ((ent >> 12 & 1u) == 0) continue;  // more joints move with this column (uniform)
+        const int it = (int)(ent >> 13);
         if (has_joint) {
             double* ts = sl + LL::TS + g * 3;
             ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
             for (int d = 0; d < 6; d++) {
                 if (d < ndep) {
-                    const double* ts = sl + LL::TS + Q->ind_dep_body[tj][d] * 3;
+                    const double* ts = sl + LL::TS + depb[d] * 3;
                     Rq += gdep[d] * ts[0]; Rv += gdep[d] * ts[1]; Ra += gdep[d] * ts[2];
                 }
             }
@@ -584,6 +607,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
         }
         wave_sync();
+        Tq = 0.0; Tv = 0.0; Ta = 0.0;
     }
 }
 

@@ -1093,6 +1093,22 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
         }
     }
 
+    // packed copies for the core kernel (device_types.h)
+    static_assert(RAPTOR_LEG_MAX_DEPTH <= 24 && RAPTOR_LEG_MAX_BODIES <= 32, "packed path / entry layout");
+    for (int g = 0; g < nb; g++)
+        for (int d = 0; d < Q.body_depth[g]; d++) Q.path8[g][d >> 3] |= (unsigned long long)Q.path[g][d] << (8 * (d & 7));
+    Q.flat_n = 0;
+    for (int t = 0; t < ni; t++)
+        for (int r = 0; r < Q.col_nsupp[t]; r++) {
+            const int k = Q.col_supp_body[t][r];
+            const unsigned ent = (unsigned)k | (unsigned)Q.body_end[k] << 5 | (unsigned)Q.col_supp_slot[t][r] << 11;
+            Q.col_pack[t][r >> 2] |= (unsigned long long)(ent | 1u << 12) << (16 * (r & 3));
+            if (Q.flat_n >= 64) throw unsupported_error("legged kernel: more than 64 (actuator, tree joint) pairs");
+            Q.flat[Q.flat_n++] = (int)(ent | (r == Q.col_nsupp[t] - 1 ? 1u << 12 : 0u) | (unsigned)t << 13);
+        }
+    for (int t = 0; t < ni; t++)
+        if (Q.col_nsupp[t] == 0) throw unsupported_error("legged kernel: an independent joint that moves no tree joint");
+
     // root body frame = T_des * endT^-1   (TalosDynamicsConstraints.cpp:34-38,214-218; Digit: rotated end transform)
     for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++) {
