@@ -686,19 +686,20 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
     }
 }
 
-// customized rows of one sample: scattered rows (the block is ordered by quantity, then by sample), each n doubles
-RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int nrows, const int* __restrict__ list,
-                           const DevCustRow* __restrict__ cust, double* __restrict__ blockbase, const double* __restrict__ rec,
-                           const double* __restrict__ wB, const int* __restrict__ tcol, const DevLegged* __restrict__ Q) {
-    const double* Pb = rec + Q->c_P;
-    const double* Ps = rec + Q->c_Psf;
+// customized rows r0 .. r0 + nrows - 1: ONE contiguous run per workgroup (a workgroup that wrote the rows of its own samples
+// would scatter 1 KB rows over the block -- the block is ordered by quantity, then sample -- which costs 15 % of the write rate of
+// the whole kernel, scripts/bw_probe.py).  A row is (ca X[qa] + cb X[qb]) differentiated: coef[r][t] per actuator t (formed in the
+// prologue from the records of the row's sample) times the order-0 Bernstein weight of its sample.
+RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int ni, const int K, const int nrows,
+                           double* __restrict__ dst, const double* __restrict__ coef, const int* __restrict__ rsample,
+                           const double* __restrict__ B0, const int* __restrict__ tcol) {
     const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
     const int total = nrows * n;
     int el = 2 * tid;
     int r = el / n, c = el - r * n;
     for (; el < total; el += 2 * LEG_EXP_BLOCK) {
-        const int row = list[r];
-        const DevCustRow cr = cust[row];
+        const double* cf = coef + r * ni;
+        const double* w = B0 + rsample[r] * K;
         double o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -706,13 +707,11 @@ RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int
             double val = 0.0;
             if (cc < ndyn) {
                 const int t = tcol[cc];
-                const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
-                const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
-                val = (cr.ca * da + cr.cb * db) * wB[cc];
+                val = cf[t] * w[cc - t * K];
             }
             o[h] = val;
         }
-        store2_stream(blockbase + (size_t)row * n + c, o[0], o[1]);
+        store2_stream(dst + el, o[0], o[1]);
         r += dr;
         c += dc;
         if (c >= n) { c -= n; r++; }
@@ -723,10 +722,8 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
                                                                      const DevLegged* __restrict__ Q,
                                                                      const double* __restrict__ basis, const DevLayout L,
                                                                      const double* __restrict__ core,
-                                                                     const DevCustRow* __restrict__ cust,
-                                                                     const int* __restrict__ cust_list,
-                                                                     const int* __restrict__ cust_start, const int spw,
-                                                                     double* __restrict__ JAC) {
+                                                                     const DevCustRow* __restrict__ cust, const int spw,
+                                                                     const int cper, double* __restrict__ JAC) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int N = T->N;
@@ -740,8 +737,13 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
     const int stride = Q->c_stride;
     double* rec = lds;                                            // [spw][stride]
     double* wB = lds + spw * stride;                              // [spw][3][ndyn]
-    int* tcol = reinterpret_cast<int*>(wB + spw * 3 * ndyn);      // [ndyn]
+    int* tcol = reinterpret_cast<int*>(wB + spw * 3 * ndyn + cper * ni + N * K);  // [ndyn]
     int* rowinfo = tcol + ndyn;                                   // [MAX_NV] row kind, then [MAX_NV][2] dep_col
+    int* rsample = rowinfo + 3 * RAPTOR_MAX_NV;                   // [cper] sample of each customized row of this workgroup's run
+    double* coef = wB + spw * 3 * ndyn;                           // [cper][ni]
+    double* B0 = coef + cper * ni;                                // [N][K] order-0 weights of every sample
+    const int r0 = (int)(blockIdx.x - b * groups) * cper;         // this workgroup's run of customized rows
+    const int crows = max(0, min(cper, Q->ncust - r0));
     const double* src = core + (size_t)e * stride;                // the records of consecutive samples are adjacent
     for (int k = tid; k < cnt * stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
     for (int c = tid; c < cnt * ndyn; c += LEG_EXP_BLOCK) {
@@ -755,6 +757,19 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
         w[2 * ndyn + cc] = Bs[2 * K];
         if (sidx == 0) tcol[cc] = t;
     }
+    for (int k = tid; k < crows * ni; k += LEG_EXP_BLOCK) {
+        const int r = k / ni, t = k - r * ni;
+        const DevCustRow cr = cust[r0 + r];
+        const double* rs = core + (size_t)(b * N + cr.sample) * stride;
+        const double* Pb = rs + Q->c_P;
+        const double* Ps = rs + Q->c_Psf;
+        const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
+        const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
+        coef[k] = cr.ca * da + cr.cb * db;
+        if (t == 0) rsample[r] = cr.sample;
+    }
+    if (crows > 0)
+        for (int k = tid; k < N * K; k += LEG_EXP_BLOCK) B0[k] = basis[(size_t)((k / K) * 3) * K + (k % K)];
     if (tid < nv) rowinfo[tid] = (Q->joint_ind[tid] >= 0) ? Q->joint_ind[tid] : -1 - Q->joint_dep[tid];
     if (tid < nd) {
         rowinfo[RAPTOR_MAX_NV + 2 * tid] = Q->dep_col[tid][0];
@@ -766,10 +781,8 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
     legged_expand_piece<0>(tid, n, ndyn, ni, ni, cnt, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, stride, wB, tcol, rowinfo, Q);
     legged_expand_piece<1>(tid, n, ndyn, ni, nv, cnt, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, stride, wB, tcol, rowinfo, Q);
     legged_expand_piece<2>(tid, n, ndyn, ni, 7, cnt, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, stride, wB, tcol, rowinfo, Q);
-    if (Q->ncust > 0)
-        for (int sidx = 0; sidx < cnt; sidx++)
-            legged_expand_cust(tid, n, ndyn, cust_start[i + sidx + 1] - cust_start[i + sidx], cust_list + cust_start[i + sidx], cust,
-                               base + (size_t)Q->off_cust * n, rec + sidx * stride, wB + sidx * 3 * ndyn, tcol, Q);
+    if (crows > 0)
+        legged_expand_cust(tid, n, ndyn, ni, K, crows, base + ((size_t)Q->off_cust + r0) * n, coef, rsample, B0, tcol);
 }
 
 // fallback for an odd number of columns: one entry per lane

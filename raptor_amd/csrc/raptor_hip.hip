@@ -654,9 +654,11 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         const int ndyn = p.hleg.ni * p.hleg.K;
         const int spw = p.htraj.N >= 2 ? 2 : 1;  // two consecutive samples per workgroup: longer contiguous pieces, half the prologues
         const int groups = (p.htraj.N + spw - 1) / spw;
-        const size_t lds_bytes = (size_t)spw * (p.hleg.c_stride + 3 * ndyn) * sizeof(double) + (size_t)(ndyn + 3 * RAPTOR_MAX_NV) * sizeof(int);
+        const int cper = (p.hleg.ncust + groups - 1) / groups;  // customized rows per workgroup: one contiguous run
+        const size_t lds_bytes = (size_t)(spw * (p.hleg.c_stride + 3 * ndyn) + cper * p.hleg.ni + p.htraj.N * p.hleg.K) * sizeof(double) +
+                                 (size_t)(ndyn + 3 * RAPTOR_MAX_NV + cper + 1) * sizeof(int);
         hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)((long long)B * groups)), dim3(LEG_EXP_BLOCK), lds_bytes, st, p.d_traj.p,
-                           p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, spw, dJ);
+                           p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, spw, cper, dJ);
     } else {
         const long long total = (long long)B * p.layout.m * p.layout.n;
         if (total / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
@@ -767,9 +769,41 @@ __global__ __launch_bounds__(256) void probe_fill_kernel(double* __restrict__ p,
     for (long long el = 2 * threadIdx.x; el < chunk; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
 }
 
+// chunk_doubles = -1: the write pattern of legged_expand_kernel on the Digit batch without its arithmetic -- a workgroup per two
+// samples of a decision vector (1005 rows x 132 columns, 14 samples): three contiguous pieces in three blocks plus 130
+// scattered rows of the customized block.  chunk_doubles = -2: the same bytes, workgroups in address order.
+__global__ __launch_bounds__(256) void probe_pattern_kernel(double* __restrict__ p, const int ordered) {
+    constexpr int n = 132, M = 1005;
+    const long long w = blockIdx.x;
+    double* zb = p + (w / 7) * (long long)M * n;
+    const int pair = (int)(w % 7);
+    if (ordered == 1) {  // 1005 rows in 7 consecutive runs
+        const int r0 = pair * 144, r1 = min(M, r0 + 144);
+        double* dst = zb + (long long)r0 * n;
+        for (int el = 2 * threadIdx.x; el < (r1 - r0) * n; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
+        return;
+    }
+    const int rows[3] = {12, 36, 7}, off[3] = {0, 14 * 12, 14 * 48};
+    for (int b = 0; b < 3; b++) {
+        double* dst = zb + (long long)(off[b] + pair * 2 * rows[b]) * n;
+        for (int el = 2 * threadIdx.x; el < 2 * rows[b] * n; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
+    }
+    double* cb = zb + (long long)(14 * 55) * n;
+    for (int el = 2 * threadIdx.x; el < 130 * n; el += 512) {
+        const int r = el / n, c = el - r * n;
+        const int row = (ordered == 2) ? pair * 34 + r : (r >> 1) * 14 + pair * 2 + (r & 1);  // quantity-major, sample-minor
+        if (ordered == 2 && r >= 34) break;
+        if (row < M - 14 * 55) *reinterpret_cast<double2*>(cb + (long long)row * n + c) = make_double2(1.0, 2.0);
+    }
+}
+
 extern "C" {
 
 int raptor_probe_fill(double* d_p, long long blocks, long long chunk_doubles, void* stream) {
+    if (chunk_doubles < 0) {
+        hipLaunchKernelGGL(probe_pattern_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, (int)(-1 - chunk_doubles));
+        return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
+    }
     hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, chunk_doubles);
     return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
 }

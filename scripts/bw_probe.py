@@ -24,3 +24,10 @@ for chunk in (8624, 8628, 8624 * 14, 1584, 4752, 924, 132):
     blocks = n // chunk
     ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), blocks, chunk, st))
     print(f"probe chunk {chunk*8/1024:.0f} KB x {blocks} blocks: {ms:.3f} ms  {blocks*chunk*8/ms/1e6:.0f} GB/s")
+
+# the Digit expand kernel's own pattern (scattered pieces) against the same bytes in address order: 4096 z x 7 workgroups
+zs = n // (1005 * 132)
+for mode, name in ((-1, "expand pattern (3 pieces + 130 scattered rows per workgroup)"), (-2, "same bytes, address order"),
+                   (-3, "3 pieces per workgroup, customized rows as one contiguous run per workgroup")):
+    ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), zs * 7, mode, st))
+    print(f"probe {name}: {ms:.3f} ms  {zs*1005*132*8/ms/1e6:.0f} GB/s")
