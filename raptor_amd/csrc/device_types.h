@@ -113,9 +113,10 @@ struct DevLegged {
     int off_tau, off_q, off_contact;          // block offsets in Optimizer row order
     int nperiod, off_period;                  // reset-map block (period_kernel.h): rows (0: absent), offset
     // per-sample-eval record written by the core kernel (doubles):
-    //   tau[ni] lambda[6] q[nv] v[nv] a[nv] | D[it][x][ni] (x = q, v, a; rows = actuators) | L[it][x][6] |
-    //   Pb[it][6] (floating-base rows of P_dep) | Pl[nd - 6][2] (closed-loop rows of P_dep, columns dep_col)
-    //   sf[6] swing-foot x y z roll pitch yaw | Psf[it][6] its derivative per unit actuator displacement
+    //   tau[ni] lambda[6] q[nv] v[nv] a[nv] | D[it][x][ni] (x = q, v, a; rows = actuators) | L[x][6][it] |
+    //   Pb[6][it] (floating-base rows of P_dep) | Pl[nd - 6][2] (closed-loop rows of P_dep, columns dep_col)
+    //   sf[6] swing-foot x y z roll pitch yaw | Psf[6][it] its derivative per unit actuator displacement
+    //   (`it` innermost where the core kernel's column lanes are the writers: their stores are runs of 8 * ni bytes)
     int c_tau, c_lam, c_q, c_v, c_a, c_D, c_L, c_P, c_Pl, c_sf, c_Psf, c_stride;
 };
 

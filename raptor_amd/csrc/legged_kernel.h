@@ -323,6 +323,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     int depb[6];  // bodies of the closed-loop joints this actuator drives
 #pragma unroll
     for (int d = 0; d < 6; d++) depb[d] = (d < ndep) ? Q->ind_dep_body[tj][d] : 0;
+    int recb[6];  // their records in the loop buffer (entry 0 beyond ndep: a valid address, weighted by zero below)
+#pragma unroll
+    for (int d = 0; d < 6; d++) recb[d] = (d < ndep) ? Q->body_rec[depb[d]] : 0;
 #pragma unroll
     for (int d = 0; d < 6; d++) {
         const int db = depb[d];
@@ -460,13 +463,18 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     // (dG^T/dq) tau_tree: an actuator's torque also changes because the loop Jacobian Y1 moves with the drivers
     double Kq[2] = {0.0, 0.0};
+    if (ndep > 0) {  // all twelve loads in flight together (a branch per joint would wait for each pair in turn)
+        double k0[6], k1[6];
 #pragma unroll
-    for (int d = 0; d < 6; d++) {
-        if (d < ndep) {
-            const int db = depb[d];
-            const double* ld = loops + ((size_t)e * Q->nrec + Q->body_rec[db]) * 10;
-            Kq[0] += ld[3 + myslot] * tdep[d];
-            Kq[1] += ld[4 + myslot] * tdep[d];
+        for (int d = 0; d < 6; d++) {
+            const double* ld = loops + ((size_t)e * Q->nrec + recb[d]) * 10;
+            k0[d] = ld[3 + myslot];
+            k1[d] = ld[4 + myslot];
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            Kq[0] += k0[d] * tdep[d];
+            Kq[1] += k1[d] * tdep[d];
         }
     }
     const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         pl[1] = w1[0];
     }
     wave_sync();
+    LEG_PHASE_END(6, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1])
 
     // ---- phase F1: column pass.  Lane t < ni = actuator column t: d(root wrench), torso twist, swing-foot twist per unit
     // (q, v, a) of actuator t, summed over the tree joints that move with it (<= 8).  These are whole-tree quantities with
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 if (Q->ncust > 0 && sb >= k && sb < kend) tws = tws + sk * g0;
             }
         }
+        LEG_PHASE_END(7, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1] + sv_sum(Fq) + sv_sum(Fv) + sv_sum(Fa) + sv_sum(twt) + sv_sum(tws))
         if (col) {
 #pragma unroll
             for (int x = 0; x < 3; x++) {  // d(lambda.tail(6)) = root wrench about the contact point, RPY rows through A_des
@@ -527,21 +537,21 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                                       Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
                                       Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
 #pragma unroll
-                for (int r = 0; r < 6; r++) rec[Q->c_L + (t * 3 + x) * 6 + r] = lm[r];
+                for (int r = 0; r < 6; r++) rec[Q->c_L + (x * 6 + r) * ni + t] = lm[r];  // [x][r][it]: the column lanes write runs of 8 * ni bytes
             }
             {   // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
                 const V3 lin = twt.l + cross(twt.a, ot);
                 const V3 rot = rpy_rates(Rt, twt.a);
                 const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
-                for (int k = 0; k < 6; k++) rec[Q->c_P + t * 6 + k] = pc[k];
+                for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + t] = pc[k];
             }
             if (Q->ncust > 0) {  // swing-foot pose derivative (FK Jacobians times pq_pz, DigitCustomizedConstraints.cpp:80-82)
                 const V3 lin = tws.l + cross(tws.a, ps);
                 const V3 rot = rpy_rates(Rs, tws.a);
                 const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
-                for (int k = 0; k < 6; k++) rec[Q->c_Psf + t * 6 + k] = pc[k];
+                for (int k = 0; k < 6; k++) rec[Q->c_Psf + k * ni + t] = pc[k];
             }
         }
     }
@@ -664,16 +674,16 @@ RD void legged_expand_piece(const int tid, const int n, const int ndyn, const in
                     } else {
                         const int dd = -1 - info;
                         double g;
-                        if (dd < 6) g = Pb[t * 6 + dd];
+                        if (dd < 6) g = Pb[dd * ni + t];
                         else g = (t == rowinfo[RAPTOR_MAX_NV + 2 * dd]) ? Pl[(dd - 6) * 2] : ((t == rowinfo[RAPTOR_MAX_NV + 2 * dd + 1]) ? Pl[(dd - 6) * 2 + 1] : 0.0);
                         val = g * B0;
                     }
                 } else {  // RectangleSurfaceContactConstraints.cpp:52-93
                     double p[6];
                     const double B1 = wB[ndyn + cc], B2 = wB[2 * ndyn + cc];
-                    const double* l = rec + Q->c_L + (t * 3) * 6;
+                    const double* l = rec + Q->c_L + t;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) p[q] = l[q] * B0 + l[6 + q] * B1 + l[12 + q] * B2;
+                    for (int q = 0; q < 6; q++) p[q] = l[q * ni] * B0 + l[(6 + q) * ni] * B1 + l[(12 + q) * ni] * B2;
                     val = contact_row(rr_, rec + Q->c_lam, p, mu, gam, Lx, Ly);
                 }
             }
@@ -763,8 +773,8 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
         const double* rs = core + (size_t)(b * N + cr.sample) * stride;
         const double* Pb = rs + Q->c_P;
         const double* Ps = rs + Q->c_Psf;
-        const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
-        const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
+        const double da = (cr.qa < 6) ? Ps[cr.qa * ni + t] : Pb[(cr.qa - 6) * ni + t];
+        const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[cr.qb * ni + t] : Pb[(cr.qb - 6) * ni + t]);
         coef[k] = cr.ca * da + cr.cb * db;
         if (t == 0) rsample[r] = cr.sample;
     }
@@ -819,21 +829,21 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_scalar_kernel(cons
             if (ti >= 0) val = (ti == t) ? B0 : 0.0;
             else {
                 const int dd = Q->joint_dep[lr];
-                if (dd < 6) val = rec[Q->c_P + t * 6 + dd] * B0;
+                if (dd < 6) val = rec[Q->c_P + dd * ni + t] * B0;
                 else val = ((t == Q->dep_col[dd][0]) ? rec[Q->c_Pl + (dd - 6) * 2] : ((t == Q->dep_col[dd][1]) ? rec[Q->c_Pl + (dd - 6) * 2 + 1] : 0.0)) * B0;
             }
         } else if (piece == 3) {
             const DevCustRow cr = cust[lr];
             const double* Pb = rec + Q->c_P;
             const double* Ps = rec + Q->c_Psf;
-            const double da = (cr.qa < 6) ? Ps[t * 6 + cr.qa] : Pb[t * 6 + cr.qa - 6];
-            const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[t * 6 + cr.qb] : Pb[t * 6 + cr.qb - 6]);
+            const double da = (cr.qa < 6) ? Ps[cr.qa * ni + t] : Pb[(cr.qa - 6) * ni + t];
+            const double db = (cr.qb < 0) ? 0.0 : ((cr.qb < 6) ? Ps[cr.qb * ni + t] : Pb[(cr.qb - 6) * ni + t]);
             val = (cr.ca * da + cr.cb * db) * B0;
         } else {
             double p[6];
-            const double* l = rec + Q->c_L + (t * 3) * 6;
+            const double* l = rec + Q->c_L + t;
 #pragma unroll
-            for (int rr = 0; rr < 6; rr++) p[rr] = l[rr] * B0 + l[6 + rr] * B1 + l[12 + rr] * B2;
+            for (int rr = 0; rr < 6; rr++) p[rr] = l[rr * ni] * B0 + l[(6 + rr) * ni] * B1 + l[(12 + rr) * ni] * B2;
             val = contact_row(lr, rec + Q->c_lam, p, Q->mu, Q->gamma, Q->Lx, Q->Ly);
         }
     }
@@ -922,9 +932,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void legged_expand_id_kernel(const De
         const int i = (int)(e % T->N);
         const double* Bs = basis + (size_t)(i * 3) * K + k;
         const double* rec = core + (size_t)e * Q->c_stride;
-        const int R = lambda_rows ? 6 : ni;
-        const double* D = rec + (lambda_rows ? Q->c_L : Q->c_D) + (t * 3) * R + lr;
-        val = D[0] * Bs[0] + D[R] * Bs[K] + D[2 * R] * Bs[2 * K];
+        // D[it][x][row] for the torques, L[x][row][it] for lambda
+        const double* D = lambda_rows ? rec + Q->c_L + lr * ni + t : rec + Q->c_D + (t * 3) * ni + lr;
+        const int step = lambda_rows ? 6 * ni : ni;
+        val = D[0] * Bs[0] + D[step] * Bs[K] + D[2 * step] * Bs[2 * K];
     }
     out[w] = val;
 }

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         if (ti >= 0) {
             for (int t = 0; t < ni; t++) { pf[t] = (ti == t) ? 1.0 : 0.0; vq[t] = 0.0; }
         } else if (dd < 6) {
-            for (int t = 0; t < ni; t++) { pf[t] = recN[Q->c_P + t * 6 + dd]; vq[t] = 0.0; }
+            for (int t = 0; t < ni; t++) { pf[t] = recN[Q->c_P + dd * ni + t]; vq[t] = 0.0; }
         } else {
             const int c0 = Q->dep_col[dd][0], c1 = Q->dep_col[dd][1];
             const double* p2 = recN + Q->c_Pl + (dd - 6) * 2;
