@@ -240,6 +240,18 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
 int raptor_constrained_id_eval_host(raptor_problem* problem, const double* Z, int B, double* q, double* v, double* a,
                                     double* tau, double* lambda, double* ptau_pz, double* plambda_pz);
 
+/*
+ * ConstrainedInverseDynamics::lambda(i) and plambda_pz(i) with ALL n_dep rows, as the reference's members hold them
+ * (KinematicsDynamics/include/ConstrainedInverseDynamics.h:44-56, src/ConstrainedInverseDynamics.cpp:154, 169-171):
+ *     lambda     [B][N][n_dep]        plambda_pz [B][N][n_dep][n]   (may be NULL)
+ * Talos / Unitree-G1: n_dep = 6, the contact wrench (the same numbers as raptor_constrained_id_eval_host).  Digit: n_dep = 24,
+ * rows 0..17 the multipliers of the closed-loop (rod) constraints in the reference's constraint order
+ * (Examples/Digit/src/DigitDynamicsConstraints.cpp:579-596), rows 18..23 the contact wrench.  Component view (host buffers,
+ * synchronous, allocates its own scratch): no constraint or cost of the reference reads rows 0..17, so raptor_eval_batch
+ * never computes them.
+ */
+int raptor_constrained_id_lambda_host(raptor_problem* problem, const double* Z, int B, double* lambda, double* plambda_pz);
+
 void raptor_problem_destroy(raptor_problem* problem);
 
 /* Optimizer::get_nlp_info (KinovaOptimizer.cpp:121-147): n = varLength, m = sum of block sizes.

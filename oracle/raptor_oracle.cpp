@@ -1665,6 +1665,27 @@ int oracle_constrained_id_eval_host(raptor_problem* pr, const double* Z, int B, 
     ORACLE_CATCH
 }
 
+// lambda(i) / plambda_pz(i) with all n_dep rows (ConstrainedInverseDynamics.cpp:154, 169-171)
+int oracle_constrained_id_lambda_host(raptor_problem* pr, const double* Z, int B, double* lambda, double* plambda_pz) {
+    ORACLE_TRY
+    if (!pr || !Z) throw std::invalid_argument("null argument");
+    Problem& p = pr->p;
+    if (p.cid.dc == nullptr) throw std::runtime_error("dcPtr_ is not defined yet!");
+    const int N = p.traj.N, n = p.n, nd = p.dc.nd;
+    for (int b = 0; b < B; b++) {
+        p.cid.compute(Z + (size_t)b * n, plambda_pz != nullptr);
+        for (int i = 0; i < N; i++) {
+            const size_t e = (size_t)b * N + i;
+            for (int j = 0; j < nd; j++) {
+                if (lambda) lambda[e * nd + j] = p.cid.lambda[i][j];
+                if (plambda_pz)
+                    for (int c = 0; c < n; c++) plambda_pz[(e * nd + j) * n + c] = p.cid.plambda_pz[i](j, c);
+            }
+        }
+    }
+    ORACLE_CATCH
+}
+
 // Costs/src/{MinimizePower,MinimizeTorque,MinimizeInitialVelocity,MinimizeInitialAcceleration}.cpp
 static void cost_compute(Problem& p, int kind, const double* z, bool deriv, double& f, std::vector<double>& grad) {
     const int N = p.traj.N, V = p.traj.varLength, Nact = p.traj.Nact;

@@ -224,7 +224,7 @@ EXPORTS = [
     "problem_destroy", "problem_layout", "problem_bounds", "problem_tspan", "eval_batch",
     "eval_batch_host", "trajectory_eval_host", "inverse_dynamics_eval_host",
     "capsule_distance_batch", "capsule_distance_batch_host", "init", "profile_begin", "profile_end",
-    "legged_problem_create", "constrained_id_eval_host", "digit_problem_create", "eval_costs", "eval_costs_host",
+    "legged_problem_create", "constrained_id_eval_host", "constrained_id_lambda_host", "digit_problem_create", "eval_costs", "eval_costs_host",
     "dual_kinova_arm_arm_batch", "dual_kinova_arm_arm_batch_host", "step_link_eval_batch", "step_link_eval_batch_host",
     "kinova_set_objective", "kinova_eval_objective", "kinova_eval_objective_host", "eval_h_batch", "eval_h_batch_host",
     "cost_hessian_host", "eval_batch_status", "eval_batch_status_host",
@@ -264,6 +264,7 @@ class CApi:
         f("init").argtypes = [C.c_int]
         f("legged_problem_create").argtypes = [vp, C.POINTER(LeggedDesc), C.POINTER(vp)]
         f("constrained_id_eval_host").argtypes = [vp, _dp, C.c_int] + [_dp] * 7
+        f("constrained_id_lambda_host").argtypes = [vp, _dp, C.c_int, _dp, _dp]
         f("digit_problem_create").argtypes = [vp, C.POINTER(DigitDesc), C.POINTER(vp)]
         f("eval_costs").argtypes = [vp, vp, C.c_int, C.c_int, _ip, vp, vp, vp]
         f("eval_costs_host").argtypes = [vp, _dp, C.c_int, C.c_int, _ip, _dp, _dp]
@@ -510,6 +511,15 @@ class ProblemHandle:
             self.handle, _ptr(Z), B, _ptr(out["q"]), _ptr(out["v"]), _ptr(out["a"]), _ptr(out["tau"]), _ptr(out["lam"]),
             _ptr(out.get("ptau_pz")), _ptr(out.get("plambda_pz"))))
         return out
+
+    def constrained_id_lambda_host(self, Z, N: int, nd: int, derivatives: bool = True):
+        """ConstrainedInverseDynamics::lambda(i) / plambda_pz(i), all n_dep rows (Digit: 18 closure multipliers, then the wrench)."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        lam = np.empty((B, N, nd))
+        dl = np.empty((B, N, nd, self.n)) if derivatives else None
+        self.api.check(self.api.fn("constrained_id_lambda_host")(self.handle, _ptr(Z), B, _ptr(lam), _ptr(dl)))
+        return lam, dl
 
     def costs_host(self, Z, kinds, derivatives: bool = True):
         """Costs::compute members f and grad_f for each cost kind (COST_* constants)."""

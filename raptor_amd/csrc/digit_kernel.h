@@ -437,4 +437,143 @@ __global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restri
     }
 }
 
+
+// The multipliers of the closure rows, ConstrainedInverseDynamics::lambda(i) / plambda_pz(i) rows 0 .. 17
+// (KinematicsDynamics/src/ConstrainedInverseDynamics.cpp:154, 169-171).  The reference solves J_dep^T lambda = tau_dep with the
+// 24 x 24 QR of J_dep; J_dep is block triangular (a closure row touches its own loop's joints only, the contact rows touch the base
+// and the stance leg), so with the contact multipliers known (the root wrench, legged_kernel.h) the rows of loop l are
+//     C_y^T lambda_l = tau_tree,y        C_y = d c_l / d y,   tau_tree = joint torques of the re-rooted tree,
+//     d lambda_l = C_y^-T ( d tau_tree,y  -  (d C_y^T) lambda_l ),   d C_y / d x_a = D^2 c [., U_a]  along the loop's own drivers only.
+// One lane per (sample-eval, leg); geometry at the root the loops kernel found (its records), tau_tree,y and its derivatives per
+// unit (q, v, a) of every actuator from the core kernel's `lamrec`.  Component view only: no constraint of the reference reads
+// these rows, so the hot path never runs this.
+//   lam  [E][nd]            rows row0 .. row0 + NY - 1 of this loop
+//   dlam [E][ni][3][nd]     d lambda / d (q, v, a) of actuator it
+template <bool TOE>
+__global__ __launch_bounds__(64) void digit_lambda_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+                                                          const double* __restrict__ basis, const int n,
+                                                          const double* __restrict__ Z, const long long total,
+                                                          const double* __restrict__ loops, const double* __restrict__ lamrec,
+                                                          const int ni, const int nd, double* __restrict__ lam,
+                                                          double* __restrict__ dlam) {
+    constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NVL = NY + NX;
+    const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (w >= total) return;
+    const int leg = (int)(w & 1);
+    const long long e = w >> 1;
+    const int N = T->N;
+    const int i = (int)(e % N);
+    const long long b = e / N;
+    const double* z = Z + b * n;
+    const DevLoop* L = &D->loop[leg][TOE ? 1 : 0];
+    const int nrec = D->recs_per_sample;
+    const double* lrec = loops + ((size_t)e * nrec + L->rec0) * DIGIT_REC;
+    const double* tr = lamrec + (size_t)e * (nrec * (1 + 3 * ni));
+
+    double th[NVL], Y1[NX][NY];
+    {
+        double qd, qdd;
+        traj_joint(T, basis, z, i, L->drv_traj[0], th[NY], qd, qdd);
+        if (TOE) traj_joint(T, basis, z, i, L->drv_traj[1], th[NY + 1], qd, qdd);
+    }
+#pragma unroll
+    for (int r = 0; r < NY; r++) {
+        th[r] = lrec[r * DIGIT_REC];
+        Y1[0][r] = lrec[r * DIGIT_REC + 1];
+        if (TOE) Y1[NX - 1][r] = lrec[r * DIGIT_REC + 2];
+    }
+    LoopSolver<NY, NX, NCL, NA, NB> S;
+    S.L = L;
+    S.geometry(th);
+    double Jm[NY][NVL];
+    S.jacobian(Jm);
+    LU<NY> lu;  // of C_y^T
+#pragma unroll
+    for (int r = 0; r < NY; r++)
+#pragma unroll
+        for (int k = 0; k < NY; k++) lu.a[k][r] = Jm[r][k];
+    lu_factor<NY>(lu);
+    double lm[NY];
+#pragma unroll
+    for (int k = 0; k < NY; k++) lm[k] = tr[L->rec0 + k];
+    lu_solve<NY>(lu, lm);
+#pragma unroll
+    for (int r = 0; r < NY; r++) lam[(size_t)e * nd + L->row0 + r] = lm[r];
+    if (dlam == nullptr) return;
+    // (d C_y^T / d x_a) lambda for the loop's own drivers: component k = lambda . D^2 c [e_k, U_a]
+    double corr[NX][NY];
+#pragma unroll
+    for (int a = 0; a < NX; a++) {
+        double U[NVL];
+#pragma unroll
+        for (int r = 0; r < NY; r++) U[r] = Y1[a][r];
+#pragma unroll
+        for (int x = 0; x < NX; x++) U[NY + x] = (x == a) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < NY; k++) {
+            double ek[NVL], dk[NY];
+#pragma unroll
+            for (int j = 0; j < NVL; j++) ek[j] = (j == k) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < NY; r++) dk[r] = 0.0;
+            S.add_D2(ek, U, dk);
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < NY; r++) s += lm[r] * dk[r];
+            corr[a][k] = s;
+        }
+    }
+    const int c0 = L->drv_traj[0], c1 = TOE ? L->drv_traj[NX - 1] : -1;
+#pragma unroll 1
+    for (int it = 0; it < ni; it++) {
+#pragma unroll 1
+        for (int x = 0; x < 3; x++) {
+            double rhs[NY];
+            const double* tsrc = tr + nrec + (it * 3 + x) * nrec + L->rec0;
+#pragma unroll
+            for (int k = 0; k < NY; k++) {
+                double v = tsrc[k];
+                if (x == 0 && it == c0) v -= corr[0][k];
+                if (TOE && x == 0 && it == c1) v -= corr[NX - 1][k];
+                rhs[k] = v;
+            }
+            lu_solve<NY>(lu, rhs);
+            double* o = dlam + (((size_t)e * ni + it) * 3 + x) * nd + L->row0;
+#pragma unroll
+            for (int r = 0; r < NY; r++) o[r] = rhs[r];
+        }
+    }
+}
+
+// ConstrainedInverseDynamics::plambda_pz(i), all nd rows, [E][nd][n]: closure rows from `dlam` (digit_lambda_kernel), the last six
+// (contact wrench) from the core kernel's records L[x][6][it]
+__global__ __launch_bounds__(RAPTOR_BLOCK) void legged_lambda_expand_kernel(const DevTraj* __restrict__ T,
+                                                                            const DevLegged* __restrict__ Q,
+                                                                            const double* __restrict__ basis, const int n,
+                                                                            const double* __restrict__ core,
+                                                                            const double* __restrict__ dlam, const long long total,
+                                                                            double* __restrict__ out) {
+    const long long w = (long long)blockIdx.x * RAPTOR_BLOCK + threadIdx.x;
+    if (w >= total) return;
+    const int nd = Q->nd, ni = Q->ni, K = Q->K;
+    const int c = (int)(w % n);
+    const long long er = w / n;
+    const int lr = (int)(er % nd);
+    const long long e = er / nd;
+    double val = 0.0;
+    if (c < ni * K) {
+        const int t = c / K, k = c - t * K;
+        const int i = (int)(e % T->N);
+        const double* Bs = basis + (size_t)(i * 3) * K + k;
+        if (lr >= nd - 6) {
+            const double* Lr = core + (size_t)e * Q->c_stride + Q->c_L + (lr - (nd - 6)) * ni + t;
+            val = Lr[0] * Bs[0] + Lr[6 * ni] * Bs[K] + Lr[12 * ni] * Bs[2 * K];
+        } else {
+            const double* d = dlam + (((size_t)e * ni + t) * 3) * nd + lr;
+            val = d[0] * Bs[0] + d[nd] * Bs[K] + d[2 * nd] * Bs[2 * K];
+        }
+    }
+    out[w] = val;
+}
+
 #endif

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
     const double* __restrict__ loops, const DevCustRow* __restrict__ cust, const int* __restrict__ cust_list,
-    const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core) {
+    const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec) {
+    // lamrec (may be null; the component view raptor_constrained_id_lambda_host only): per sample-eval the tree torque of every
+    // closed-loop joint and its derivative per unit (q, v, a) of every actuator,  tau[nrec] | T[it][x][nrec]
     extern __shared__ double lds[];
     using LL = LegLds<LG>;
     constexpr int EPB = LEG_BLOCK / LG;
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
     // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
     const double tt = has_joint ? dot(s, F) + arm_j * qdd + damp_j * qd : 0.0;
+    if (lamrec != nullptr && rc >= 0) lamrec[(size_t)e * (Q->nrec * (1 + 3 * ni)) + rc] = tt;
     if (has_joint) {
         rec[Q->c_q + jnt] = q;
         rec[Q->c_v + jnt] = qd;
@@ -600,6 +603,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         if (has_joint) {
             double* ts = sl + LL::TS + g * 3;
             ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
+        }
+        if (lamrec != nullptr && rc >= 0) {
+            const int nrec = Q->nrec;
+            double* o = lamrec + (size_t)e * (nrec * (1 + 3 * ni)) + nrec + (it * 3) * nrec + rc;
+            o[0] = Tq; o[nrec] = Tv; o[2 * nrec] = Ta;
         }
         wave_sync();
         if (tj >= 0) {  // project the rows: G^T

@@ -577,7 +577,7 @@ void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, 
 }
 
 // core kernel (values + compact derivative records), then the streaming expansion into pg_pz
-void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st) {
+void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st, double* d_lamrec = nullptr) {
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
     p.s_core.ensure((size_t)E * p.hleg.c_stride);
@@ -601,7 +601,7 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
 #define LEG_LAUNCH(LGV, DV)                                                                                          \
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
-                       p.d_cust_start.p, dG, p.s_core.p)
+                       p.d_cust_start.p, dG, p.s_core.p, d_lamrec)
     if (wide) {
         if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
     } else {
@@ -1612,6 +1612,59 @@ int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, d
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(dst, p->s_J.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    API_CATCH
+}
+
+int raptor_constrained_id_lambda_host(raptor_problem* p, const double* Z, int B, double* lambda, double* plambda_pz) {
+    API_TRY
+    if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    if (p->kind != 2) throw std::runtime_error("dcPtr_ is not defined yet!");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    const DevLegged& Q = p->hleg;
+    const int N = p->htraj.N, n = p->layout.n, ni = Q.ni, nd = Q.nd, nrec = Q.nrec;
+    const bool deriv = plambda_pz != nullptr;
+    const size_t E = (size_t)B * N;
+    p->s_Z.upload(Z, (size_t)B * n);
+    DevBuf<double> lamrec, lam, dlam;  // component view: buffers of the call
+    if (nrec > 0) {
+        lamrec.ensure(E * nrec * (1 + 3 * ni));
+        lam.ensure(E * nd);
+        if (deriv) dlam.ensure(E * ni * 3 * nd);
+    }
+    launch_legged_core(*p, p->s_Z.p, B, nullptr, deriv, nullptr, lamrec.p);
+    if (nrec > 0) {
+        if (!p->has_digit) throw unsupported_error("closure multipliers: Digit's loops only");
+        const long long total = (long long)E * 2;
+        const unsigned lgrid = (unsigned)((total + 63) / 64);
+        hipLaunchKernelGGL((digit_lambda_kernel<false>), dim3(lgrid), dim3(64), 0, nullptr, p->d_traj.p, p->d_digit.p, p->d_basis.p, n,
+                           p->s_Z.p, total, p->s_loops.p, lamrec.p, ni, nd, lam.p, deriv ? dlam.p : nullptr);
+        hipLaunchKernelGGL((digit_lambda_kernel<true>), dim3(lgrid), dim3(64), 0, nullptr, p->d_traj.p, p->d_digit.p, p->d_basis.p, n,
+                           p->s_Z.p, total, p->s_loops.p, lamrec.p, ni, nd, lam.p, deriv ? dlam.p : nullptr);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    if (lambda) {
+        std::vector<double> rec(E * Q.c_stride), lh;
+        HIP_CHECK(hipMemcpy(rec.data(), p->s_core.p, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) {
+            lh.resize(E * nd);
+            HIP_CHECK(hipMemcpy(lh.data(), lam.p, lh.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        for (size_t e = 0; e < E; e++) {
+            for (int j = 0; j < nd - 6; j++) lambda[e * nd + j] = lh[e * nd + j];
+            for (int j = 0; j < 6; j++) lambda[e * nd + nd - 6 + j] = rec[e * Q.c_stride + Q.c_lam + j];
+        }
+    }
+    if (deriv) {
+        const long long total = (long long)E * nd * n;
+        p->s_J.ensure((size_t)total);
+        hipLaunchKernelGGL(legged_lambda_expand_kernel, dim3(grid_for(total)), dim3(RAPTOR_BLOCK), 0, nullptr, p->d_traj.p, p->d_leg.p,
+                           p->d_basis.p, n, p->s_core.p, dlam.p, total, p->s_J.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(plambda_pz, p->s_J.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
     }
     API_CATCH
 }

@@ -421,6 +421,45 @@ def test_digit_constrained_inverse_dynamics(oracle, hip, stance):
         check(rh2[key], ro[key])
 
 
+@pytest.mark.parametrize("stance", ["L", "R"])
+def test_digit_full_lambda(oracle, hip, stance):
+    """ConstrainedInverseDynamics::lambda(i) / plambda_pz(i) with all 24 rows (ConstrainedInverseDynamics.cpp:154, 169-171):
+    the 18 multipliers of the rod closures (block-triangular solves per loop on the GPU, the reference's 24 x 24 QR in the oracle),
+    then the contact wrench.  The closure rows follow the oracle's row form of get_c / get_J."""
+    N = 5
+    keep = []
+    po, m, cfg = H.digit_problem(oracle, keep, N=N, stance=stance)
+    ph, _, _ = H.digit_problem(hip, keep, N=N, stance=stance)
+    rng = np.random.default_rng(20250523 + 14)
+    Z = 0.1 * rng.uniform(-1, 1, (4, po.n))
+    lo, dlo = po.constrained_id_lambda_host(Z, N, 24)
+    lh, dlh = ph.constrained_id_lambda_host(Z, N, 24)
+    assert np.abs(lo[..., :18]).max() > 1.0  # the rods carry load: the comparison is not of zeros
+    check(lh, lo)
+    check(dlh, dlo)
+    assert np.all(dlh[..., 72:] == 0) and np.all(dlo[..., 72:] == 0)
+    # the last six rows are the view raptor_constrained_id_eval_host returns
+    rh = ph.constrained_id_host(Z, N, 36, 12)
+    assert np.array_equal(lh[..., 18:], rh["lam"]) and np.array_equal(dlh[..., 18:, :], rh["plambda_pz"])
+    lh2, none = ph.constrained_id_lambda_host(Z, N, 24, derivatives=False)
+    check(lh2, lo)
+
+
+@pytest.mark.parametrize("which", ["talos", "g1"])
+def test_legged_full_lambda(oracle, hip, which):
+    """n_dep = 6: the all-rows view is the contact wrench."""
+    N = 4
+    keep = []
+    po, m, cfg = H.legged_problem(oracle, which, keep, N=N)
+    ph, _, _ = H.legged_problem(hip, which, keep, N=N)
+    rng = np.random.default_rng(20250523 + 15)
+    Z = 0.3 * rng.uniform(-1, 1, (3, po.n))
+    lo, dlo = po.constrained_id_lambda_host(Z, N, 6)
+    lh, dlh = ph.constrained_id_lambda_host(Z, N, 6)
+    check(lh, lo)
+    check(dlh, dlo)
+
+
 def test_digit_eval_g_and_jac(oracle, hip):
     """eval_g / eval_jac_g of DigitSingleStepOptimizer's first three blocks at the example's size (N = 14, degree 5)."""
     keep = []
