@@ -268,19 +268,24 @@ struct LoopSolver {
     }
 };
 
-// One lane per (sample-eval, leg).  TOE = false: knee loops (NY 3, NX 1), TOE = true: toe loops (NY 6, NX 2).
+// One lane per (sample-eval, leg); `total` = sample-evals, grid = 2 x ceil(total / 64).  TOE = false: knee loops (NY 3, NX 1), TOE = true: toe loops (NY 6, NX 2).
+#ifndef DIGIT_LOOPS_OCC
+#define DIGIT_LOOPS_OCC 1
+#endif
 template <bool TOE>
-__global__ __launch_bounds__(64) void digit_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+__global__ __launch_bounds__(64, DIGIT_LOOPS_OCC) void digit_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
                                                          const double* __restrict__ basis, const int n,
                                                          const double* __restrict__ Z, const long long total,
                                                          double* __restrict__ loops, int* __restrict__ status,
                                                          int* __restrict__ iterations) {
     constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NS = NX * (NX + 1) / 2,
                   NT = NX * (NX + 1) * (NX + 2) / 6;
-    const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (w >= total) return;
-    const int leg = (int)(w & 1);
-    const long long e = w >> 1;
+    // a wavefront works on ONE leg (blockIdx parity), so the loop's constants -- placements, end points, initial-guess tables -- sit
+    // behind a uniform pointer and come through scalar loads into SGPR operands; with the leg taken from the lane index they were
+    // ~180 vector loads (and 41 waits) in every Newton step
+    const int leg = (int)(blockIdx.x & 1);
+    const long long e = (long long)(blockIdx.x >> 1) * 64 + threadIdx.x;
+    if (e >= total) return;
     const int N = T->N;
     const int i = (int)(e % N);
     const long long b = e / N;

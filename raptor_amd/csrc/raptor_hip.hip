@@ -584,12 +584,11 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const double* d_loops = nullptr;
     if (p.has_digit) {  // closed loops first: one lane per (sample-eval, leg), knee and toe loops in separate launches
         p.s_loops.ensure((size_t)E * p.hleg.nrec * DIGIT_REC);
-        const long long total = E * 2;
-        const unsigned lgrid = (unsigned)((total + 63) / 64);
+        const unsigned lgrid = 2 * (unsigned)((E + 63) / 64);  // a wavefront per (64 sample-evals, leg)
         hipLaunchKernelGGL((digit_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, total, p.s_loops.p, p.cur_status, p.cur_iterations);
+                           p.layout.n, dZ, E, p.s_loops.p, p.cur_status, p.cur_iterations);
         hipLaunchKernelGGL((digit_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, total, p.s_loops.p, p.cur_status, p.cur_iterations);
+                           p.layout.n, dZ, E, p.s_loops.p, p.cur_status, p.cur_iterations);
         HIP_CHECK(hipGetLastError());
         d_loops = p.s_loops.p;
     }
