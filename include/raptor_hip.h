@@ -280,6 +280,20 @@ int raptor_eval_batch_host(raptor_problem* problem, const double* Z, int B, unsi
                            double* G, double* JAC);
 
 /*
+ * Multi-start support (no counterpart in the reference, which solves one problem per process).
+ * raptor_shard_range: the block partition of `total` independent problems over `world` ranks (one process per GPU): rank r
+ *   owns [first, first + count), blocks of ceil(total / world), the last ones short or empty.  Pure arithmetic, no GPU.
+ * raptor_violation_batch: the per-problem record the ranks exchange -- the worst bound violation of each decision vector,
+ *   d_violation[b] = max_r max(g_lb[r] - g[b][r], g[b][r] - g_ub[r], 0), NaN if a row is NaN; a problem is feasible in the
+ *   sense of Optimizer::eval_g (Optimization/src/Optimizer.cpp:374-378) when d_violation[b] <= constr_viol_tol.
+ *   d_G = the [B x m] output of raptor_eval_batch; asynchronous on hip_stream, stream-ordered after the call that wrote d_G.
+ *   The first call on a problem uploads its bounds (one allocation).
+ * A C++ host gathers d_violation (B doubles per rank, padded to ceil(total / world)) with one ncclAllGather: INTEGRATION.md.
+ */
+int raptor_shard_range(long long total, int world, int rank, long long* first, long long* count);
+int raptor_violation_batch(raptor_problem* problem, const double* d_G, int B, double* d_violation, void* hip_stream);
+
+/*
  * raptor_eval_batch plus a per-z report of the dependent-joint root finding (SURVEY.md 8b `int* status`).  The reference
  * runs gsl_multiroot_fdfsolver_hybridsj for at most 50 iterations per time sample and silently accepts whatever it holds at the
  * end (Examples/Digit/src/DigitDynamicsConstraints.cpp:344-367); so does this library -- the rows of a z whose closed loops

@@ -232,7 +232,7 @@ EXPORTS = [
 STATUS_NOT_CONVERGED = 1
 STATUS_NONFINITE = 2
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
-DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc"]
+DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc", "shard_range", "violation_batch"]
 
 
 class CApi:
@@ -287,11 +287,19 @@ class CApi:
         if prefix == "raptor_":
             f("probe_fill").argtypes = [vp, C.c_longlong, C.c_longlong, vp]
             f("eval_h_batch_noalloc").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+            f("shard_range").argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+            f("violation_batch").argtypes = [vp, vp, C.c_int, vp, vp]
         self._f = f
 
     # -- helpers -------------------------------------------------------------------------
     def fn(self, name: str):
         return self._f(name)
+
+    def shard_range(self, total: int, world: int, rank: int):
+        """raptor_shard_range: (first, count) of the block of `total` problems that `rank` of `world` owns."""
+        first, count = C.c_longlong(), C.c_longlong()
+        self.check(self._f("shard_range")(total, world, rank, C.byref(first), C.byref(count)))
+        return first.value, count.value
 
     def check(self, code: int) -> None:
         if code == RAPTOR_OK:
@@ -610,6 +618,10 @@ class ProblemHandle:
     def eval_device(self, d_Z: int, B: int, flags: int, d_G: int, d_JAC: int, stream: int = 0) -> None:
         """Raw device pointers (ints), asynchronous on ``stream``."""
         self.api.check(self.api.fn("eval_batch")(self.handle, d_Z, B, flags, d_G or None, d_JAC or None, stream or None))
+
+    def violation_device(self, d_G: int, B: int, d_violation: int, stream: int = 0) -> None:
+        """raptor_violation_batch: worst bound violation per decision vector from the [B x m] rows at d_G (device pointers)."""
+        self.api.check(self.api.fn("violation_batch")(self.handle, d_G, B, d_violation, stream or None))
 
     def profile_begin(self, max_evaluations: int) -> None:
         self.api.check(self.api.fn("profile_begin")(self.handle, max_evaluations))

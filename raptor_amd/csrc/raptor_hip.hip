@@ -136,6 +136,7 @@ struct raptor_problem {
     DevLegged hleg;
     DevBuf<DevLegged> d_leg;
     DevBuf<double> s_core;  // per-sample records of the legged core kernel (grown on demand, reused)
+    DevBuf<double> d_glb, d_gub;  // the bounds on the device (raptor_violation_batch, uploaded on its first call)
     bool has_digit = false;
     DevBuf<DevDigit> d_digit;
     DevBuf<double> s_loops;  // per-sample closed-loop records (digit_kernel.h)
@@ -766,6 +767,35 @@ void launch_copy2(double* d0, const double* s0, size_t n0, double* d1, const dou
 __global__ __launch_bounds__(256) void probe_fill_kernel(double* __restrict__ p, const long long chunk) {
     double* dst = p + (long long)blockIdx.x * chunk;
     for (long long el = 2 * threadIdx.x; el < chunk; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
+}
+
+// worst bound violation of each decision vector: max over the rows of max(g_lb - g, g - g_ub, 0); NaN if a row is NaN.
+// One workgroup per z, fixed reduction order (deterministic).
+__global__ __launch_bounds__(RAPTOR_BLOCK) void violation_kernel(const double* __restrict__ G, const double* __restrict__ lb,
+                                                                 const double* __restrict__ ub, const int m,
+                                                                 double* __restrict__ out) {
+    __shared__ double red[RAPTOR_BLOCK];
+    __shared__ int bad[RAPTOR_BLOCK];
+    const double* g = G + (size_t)blockIdx.x * m;
+    double v = 0.0;
+    int nan = 0;
+    for (int r = threadIdx.x; r < m; r += RAPTOR_BLOCK) {
+        const double x = g[r];
+        const double d = fmax(lb[r] - x, x - ub[r]);
+        if (x != x) nan = 1;
+        v = fmax(v, d);
+    }
+    red[threadIdx.x] = v;
+    bad[threadIdx.x] = nan;
+    __syncthreads();
+    for (int s = RAPTOR_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+            bad[threadIdx.x] |= bad[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = bad[0] ? __longlong_as_double(0x7ff8000000000000LL) : red[0];
 }
 
 // chunk_doubles = -1: the write pattern of legged_expand_kernel on the Digit batch without its arithmetic -- a workgroup per two
@@ -1700,6 +1730,31 @@ int raptor_eval_batch(raptor_problem* p, const double* d_Z, int B, unsigned flag
     API_TRY
     if (!p) throw std::invalid_argument("null problem");
     eval_device(*p, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    API_CATCH
+}
+
+int raptor_shard_range(long long total, int world, int rank, long long* first, long long* count) {
+    API_TRY
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !first || !count) throw std::invalid_argument("bad shard arguments");
+    const long long per = (total + world - 1) / world;
+    const long long lo = std::min((long long)rank * per, total);
+    *first = lo;
+    *count = std::min(lo + per, total) - lo;
+    API_CATCH
+}
+
+int raptor_violation_batch(raptor_problem* p, const double* d_G, int B, double* d_violation, void* stream) {
+    API_TRY
+    if (!p || (B > 0 && (!d_G || !d_violation))) throw std::invalid_argument("null argument");
+    if (B < 0) throw std::invalid_argument("B < 0");
+    if (B == 0) return RAPTOR_OK;
+    if (!p->d_glb.p) {
+        p->d_glb.upload(p->g_lb.data(), p->g_lb.size());
+        p->d_gub.upload(p->g_ub.data(), p->g_ub.size());
+    }
+    hipLaunchKernelGGL(violation_kernel, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_G, p->d_glb.p, p->d_gub.p,
+                       p->layout.m, d_violation);
+    HIP_CHECK(hipGetLastError());
     API_CATCH
 }
 

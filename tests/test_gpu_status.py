@@ -54,3 +54,32 @@ def test_status_is_zero_without_a_root_finder(oracle, hip, kinova):
         check(Jh, Jo)
     ph = H.kinova_problem(hip, kinova, keep, N=4)
     assert hip.fn("eval_batch_status_host")(ph.handle, None, 1, A.EVAL_G, None, None, None, None) == A.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_violation_record_on_device(hip):
+    """raptor_violation_batch against the formula of multistart.violation (the record the ranks gather), NaN rows included."""
+    import torch
+
+    from raptor_amd import multistart
+
+    keep = []
+    ph, m, cfg = H.legged_problem(hip, "g1", keep, N=6)
+    rng = np.random.default_rng(5)
+    Z = torch.tensor(0.3 * rng.uniform(-1, 1, (9, ph.n))).cuda()
+    G = torch.empty(9, ph.m, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ph.eval_device(Z.data_ptr(), 9, A.EVAL_G, G.data_ptr(), 0, st)
+    lb, ub = ph.bounds()
+    G[3, 17] = float("nan")
+    flo, fhi = lb > -1e18, ub < 1e18
+    inside = np.where(flo & fhi, 0.5 * (lb + ub), np.where(flo, lb + 1.0, np.where(fhi, ub - 1.0, 0.0)))
+    G[5] = torch.tensor(inside).cuda()  # inside every bound: exactly feasible
+    v = torch.full((9,), -1.0, dtype=torch.float64, device="cuda")
+    ph.violation_device(G.data_ptr(), 9, v.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref = multistart.violation(G, torch.tensor(lb).cuda(), torch.tensor(ub).cuda())
+    assert torch.isnan(v[3]) and torch.isnan(ref[3])
+    keep_rows = [0, 1, 2, 4, 5, 6, 7, 8]
+    assert torch.equal(v[keep_rows], ref[keep_rows])
+    assert v[5].item() == 0.0 and v[0].item() > 0.0

@@ -99,3 +99,25 @@ def test_timed_sweep_two_ranks(tmp_path):
         assert torch.equal(r["violation"], want) and torch.equal(r["feasible"], want <= 1e-4)
         assert r["calls"] == [block] * 4  # one warm-up + three timed sweeps, own block only
     assert r0["per_rank_s"] == r1["per_rank_s"]
+
+
+def test_shard_range_matches_c_abi():
+    """raptor_shard_range (the C-ABI partition a C++ host uses) and multistart.shard_range are the same function."""
+    import os
+
+    from raptor_amd import _capi, multistart
+
+    api = _capi.CApi(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raptor_amd", "libraptor_hip.so"), "raptor_")
+    for total in (0, 1, 7, 8, 9, 1000, 8192):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for rank in range(world):
+                first, count = api.shard_range(total, world, rank)
+                lo, hi = multistart.shard_range(total, world, rank)
+                assert (first, first + count) == (lo, hi)
+                covered += count
+            assert covered == total
+    import pytest
+
+    with pytest.raises(_capi.RaptorInvalidArgument):
+        api.shard_range(5, 2, 2)
