@@ -483,8 +483,17 @@ def run_rank(args) -> None:
                 prob.eval_device(Zb.data_ptr(), Zb.shape[0], flags, G.data_ptr(), J.data_ptr(), stream)
                 return G[:Zb.shape[0]]
 
+            viol = torch.empty(per, dtype=torch.float64, device="cuda")
+
+            def violation_native(Gb):  # the record through the library's own kernel (raptor_violation_batch)
+                prob.violation_device(Gb.data_ptr(), Gb.shape[0], viol.data_ptr(), stream)
+                return viol[:Gb.shape[0]]
+
             spinup(lambda: evaluate(Z_all[lo:hi]))
-            r = timed_sweep(evaluate, Z_all, lb, ub, args.steps, args.warmup, sync=torch.cuda.synchronize)
+            r = timed_sweep(evaluate, Z_all, lb, ub, args.steps, args.warmup, sync=torch.cuda.synchronize, violation_fn=violation_native)
+            check_v = violation_native(evaluate(Z_all[lo:hi])).clone()
+            from raptor_amd.multistart import violation as violation_torch
+            assert torch.equal(check_v, violation_torch(G[:hi - lo], lb, ub)), "raptor_violation_batch differs from the torch formula"
             # the evaluation alone (no record, no collective), for the split of the sweep time
             barrier()
             t0 = time.perf_counter()

@@ -36,10 +36,13 @@ def violation(G: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor) -> torch.
 
 def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor,
                      g_ub: torch.Tensor, constr_viol_tol: float = 1e-4, gather_g: bool = False,
-                     group=None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+                     group=None, violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Evaluate this rank's block of `Z_all` with `evaluate` (Z_block -> G_block, on this rank's device) and gather
     per-problem records on every rank.
 
+    `violation_fn` (G_block -> violation per problem) replaces the torch formula of `violation`, e.g. by the library's own
+    kernel (`ProblemHandle.violation_device` = raptor_violation_batch).
     Returns (violation[B], feasible[B] (bool), G[B, m] or None), identical on all ranks.
     """
     import torch.distributed as dist
@@ -57,7 +60,7 @@ def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: to
     rec = torch.zeros((per, width), dtype=torch.float64, device=dev)
     n = hi - lo
     if n > 0:
-        rec[:n, 0] = violation(G, g_lb.to(dev), g_ub.to(dev))
+        rec[:n, 0] = violation_fn(G) if violation_fn is not None else violation(G, g_lb.to(dev), g_ub.to(dev))
         if gather_g:
             rec[:n, 1:] = G
     if world > 1:
@@ -107,7 +110,8 @@ def select_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], cost: Calla
 
 
 def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor,
-                steps: int, warmup: int, sync: Optional[Callable[[], None]] = None, constr_viol_tol: float = 1e-4, group=None) -> dict:
+                steps: int, warmup: int, sync: Optional[Callable[[], None]] = None, constr_viol_tol: float = 1e-4, group=None,
+                violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> dict:
     """The multi-start sweep as a measured job: `steps` timed passes of `evaluate_sharded` (own block evaluated, per-problem
     record built, ONE all-gather) between barriers, after `warmup` untimed ones.  `sync` waits for this rank's device
     (torch.cuda.synchronize on a GPU; None on the CPU).  Returns, identically on every rank,
@@ -126,11 +130,11 @@ def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.T
 
     out = None
     for _ in range(max(warmup, 0)):
-        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group)
+        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group)
+        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn)
     barrier()
     dt = time.perf_counter() - t0
     dev = out[0].device if out is not None else Z_all.device
