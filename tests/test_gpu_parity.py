@@ -112,6 +112,26 @@ def test_kinova_eval_g_and_jac(oracle, hip, kinova, env, gripper):
     assert np.array_equal(Jh2, Jh)
 
 
+@pytest.mark.parametrize("O", [1, 2, 3, 33, 40])
+@pytest.mark.parametrize("gripper", [False, True])
+def test_kinova_obstacle_counts(oracle, hip, kinova, O, gripper):
+    """Obstacle counts around the kernels' internal limits: fewer boxes than the split tail needs, odd counts (the box loop walks
+    two at a time), and more than the 32 whose constants the fused kernel keeps in LDS (the winner is then rebuilt from global
+    memory).  eval_g, eval_jac_g and the Lagrangian Hessian."""
+    boxes = H.reach_boxes(seed=20250600 + O, O=O)
+    po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=9, boxes=boxes, gripper=gripper))
+    rng = np.random.default_rng(20250523 + O)
+    Z = rng.uniform(-1, 1, (7, 7))
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+    lam = rng.uniform(-1, 1, (7, po.m))
+    for p_ in (po, ph):
+        p_.set_objective(np.zeros(7), 4)
+    check(ph.eval_h_host(Z, lam, 1.0), po.eval_h_host(Z, lam, 1.0), 1e-9)
+
+
 def test_kinova_points_inside_boxes(oracle, hip, kinova):
     """Large boxes swallowing the arm: the inside branch (negative distance, snapped face) on most rows."""
     boxes = (np.array([[0.0, 0.0, 0.6], [0.3, 0.1, 0.9]]), np.array([[0.3, -0.2, 0.5], [0.0, 0.0, 0.0]]),
