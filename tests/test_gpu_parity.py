@@ -480,6 +480,29 @@ def test_legged_full_lambda(oracle, hip, which):
     check(dlh, dlo)
 
 
+@pytest.mark.parametrize("which,N", [("g1", 3), ("g1", 15), ("g1", 33), ("digit", 3), ("digit", 15), ("digit", 33)])
+def test_legged_sample_counts(oracle, hip, which, N):
+    """Sample counts that are odd, tiny or larger than the example's 14, every block on (customized rows and the reset map
+    included), and a batch that leaves the last wavefront of the record kernel partly filled: the row pieces of the expansion
+    kernel (two samples per workgroup, a run of customized rows each) and the lane groups past the end of the batch."""
+    keep = []
+    if which == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=N, customized=True, periodic=True)
+        ph, _, _ = H.digit_problem(hip, keep, N=N, customized=True, periodic=True)
+        scale = 0.1
+    else:
+        po, m, cfg = H.legged_problem(oracle, which, keep, N=N, customized=True, periodic=True)
+        ph, _, _ = H.legged_problem(hip, which, keep, N=N, customized=True, periodic=True)
+        scale = 0.3
+    assert (ph.n, ph.m, ph.block_offsets) == (po.n, po.m, po.block_offsets)
+    rng = np.random.default_rng(20250523 + N)
+    Z = scale * rng.uniform(-1, 1, (3, po.n))
+    Go, Jo = po.eval_host(Z)
+    Gh, Jh = ph.eval_host(Z)
+    check(Gh, Go)
+    check(Jh, Jo)
+
+
 def test_digit_eval_g_and_jac(oracle, hip):
     """eval_g / eval_jac_g of DigitSingleStepOptimizer's first three blocks at the example's size (N = 14, degree 5)."""
     keep = []
