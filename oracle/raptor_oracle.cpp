@@ -15,7 +15,9 @@
 // forward-mode sweep of the same file seeded with identity (what computeRNEADerivatives returns
 // mathematically).  Pinning: the nine TaperedCapsule known answers of the reference's tests plus the
 // reference's finite-difference recipes (tests/test_oracle_*.py); for d(tau)/d(q,v,a), model
-// building and anything else without a golden vector in the reference: PARITY UNPINNED.
+// building and anything else without a golden vector in the reference: PARITY UNPINNED -- except the Digit path, which the
+// reference's one shipped data file (Examples/Digit/data/initial-digit-two-step-5.txt, a converged two-step gait) pins at the
+// reference solver's tolerance: every equality row of both steps and both links <= 5e-5 (tests/test_reference_solution_pin.py).
 // =====================================================================================
 #include <algorithm>
 #include <array>

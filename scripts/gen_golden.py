@@ -23,6 +23,21 @@ from test_oracle_pins import CAPSULE_KNOWN
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def reference_two_step_z():
+    """The one data file of the reference that belongs to this path: the two-step Digit decision vector of
+    Examples/Digit/data/initial-digit-two-step-5.txt (264 numbers, read as text), stored verbatim with its settings.  It turns out
+    to be a converged periodic two-step gait: tests/test_reference_solution_pin.py checks that it satisfies this repository's
+    equality rows to the reference solver's tolerance."""
+    src = "/root/reference/Examples/Digit/data/initial-digit-two-step-5.txt"
+    if not os.path.exists(src):
+        return
+    z = np.loadtxt(src)
+    dst = os.path.join(OUT, "digit_two_step_reference_z.json")
+    old = json.load(open(dst)) if os.path.exists(dst) else {}
+    old["z"] = [repr(float(x)) for x in z]
+    json.dump(old, open(dst, "w"), indent=0)
+
+
 def kinova_hessian(oracle, kin, keep):
     """KinovaOptimizer objective + Optimizer::eval_h at fixed (z, lambda, obj_factor): regression vectors of the oracle after
     tests/test_oracle_hessian.py pinned it with the reference's finite-difference recipes."""
@@ -81,4 +96,5 @@ def main():
 
 
 if __name__ == "__main__":
+    reference_two_step_z()
     main()
