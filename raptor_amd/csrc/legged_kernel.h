@@ -568,17 +568,20 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // the second case); both vector triples sit 18 doubles apart in the LDS slots, so the choice is an address offset.
     // The (column, joint) pairs come from one packed table, a lane each, read with v_readlane: no memory access decides
     // what the next step works on.
+    // Two columns that share joints (Digit's toe_A / toe_B drive the same six joints of a toe loop) are walked TOGETHER, with two
+    // accumulator sets: the pair quantities (five dot products, 18 doubles from LDS) of a shared joint do not depend on the column
+    // and are formed once (42 -> 30 steps for Digit).  Entry: body | end << 5 | slot << 11 | last << 12 | mode << 13 | column of set 0
+    // << 15 | column of set 1 << 19 (15: none); mode 0 / 1: into set 0 / 1 with weight slot `slot`, 2: into both, slot 0 / slot 1.
     const int flat = Q->flat[tid];
     const int nflat = Q->flat_n;
-    double Tq = 0.0, Tv = 0.0, Ta = 0.0;
+    double Tq = 0.0, Tv = 0.0, Ta = 0.0, Xq = 0.0, Xv = 0.0, Xa = 0.0;
 #pragma unroll 1
     for (int idx = 0; idx < nflat; idx++) {
         const unsigned ent = (unsigned)__builtin_amdgcn_readlane(flat, idx);
         const int k = (int)(ent & 31u), kend = (int)(ent >> 5 & 63u);
         const bool s1 = (ent >> 11 & 1u) != 0;  // uniform
+        const unsigned mode = ent >> 13 & 3u;   // uniform
         {
-            const double g0 = __shfl(s1 ? w1[0] : w0[0], k, LG), hv = __shfl(s1 ? w1[1] : w0[1], k, LG),
-                         hq = __shfl(s1 ? w1[2] : w0[2], k, LG);
             const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
             const bool dsc = has_joint && g >= k && g < kend;    // k is this joint or one of its ancestors
             const double* vk = sl + LL::V + k * LEG_VEC + (anc ? 18 : 0);
@@ -594,38 +597,56 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             dv += own * damp_j;
             const double rel = (anc || dsc) ? 1.0 : 0.0;
             da *= rel; dv *= rel; dq *= rel;
-            Ta += da * g0;
-            Tv += dv * g0 + da * hv;
-            Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
-        }
-        if ((ent >> 12 & 1u) == 0) continue;  // more joints move with this column (uniform)
-        const int it = (int)(ent >> 13);
-        if (has_joint) {
-            double* ts = sl + LL::TS + g * 3;
-            ts[0] = Tq; ts[1] = Tv; ts[2] = Ta;
-        }
-        if (lamrec != nullptr && rc >= 0) {
-            const int nrec = Q->nrec;
-            double* o = lamrec + (size_t)e * (nrec * (1 + 3 * ni)) + nrec + (it * 3) * nrec + rc;
-            o[0] = Tq; o[nrec] = Tv; o[2 * nrec] = Ta;
-        }
-        wave_sync();
-        if (tj >= 0) {  // project the rows: G^T
-            double Rq = Tq, Rv = Tv, Ra = Ta;
-#pragma unroll
-            for (int d = 0; d < 6; d++) {
-                if (d < ndep) {
-                    const double* ts = sl + LL::TS + depb[d] * 3;
-                    Rq += gdep[d] * ts[0]; Rv += gdep[d] * ts[1]; Ra += gdep[d] * ts[2];
-                }
+            if (mode != 1u) {  // set 0
+                const bool sb = (mode == 2u) ? false : s1;
+                const double g0 = __shfl(sb ? w1[0] : w0[0], k, LG), hv = __shfl(sb ? w1[1] : w0[1], k, LG),
+                             hq = __shfl(sb ? w1[2] : w0[2], k, LG);
+                Ta += da * g0;
+                Tv += dv * g0 + da * hv;
+                Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
             }
-            if (it == lc0) Rq += Kq[0];
-            if (it == lc1) Rq += Kq[1];
-            double* D = rec + Q->c_D + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
-            D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
+            if (mode != 0u) {  // set 1
+                const bool sb = (mode == 2u) ? true : s1;
+                const double g0 = __shfl(sb ? w1[0] : w0[0], k, LG), hv = __shfl(sb ? w1[1] : w0[1], k, LG),
+                             hq = __shfl(sb ? w1[2] : w0[2], k, LG);
+                Xa += da * g0;
+                Xv += dv * g0 + da * hv;
+                Xq += dq * g0 + dv * (0.5 * hv) + da * hq;
+            }
         }
-        wave_sync();
-        Tq = 0.0; Tv = 0.0; Ta = 0.0;
+        if ((ent >> 12 & 1u) == 0) continue;  // more joints move with this column / pair of columns (uniform)
+#pragma unroll 1
+        for (int set = 0; set < 2; set++) {
+            const int it = (int)(set == 0 ? (ent >> 15 & 15u) : (ent >> 19 & 15u));
+            if (it == 15) continue;  // uniform
+            const double Sq = set == 0 ? Tq : Xq, Sv = set == 0 ? Tv : Xv, Sa = set == 0 ? Ta : Xa;
+            if (has_joint) {
+                double* ts = sl + LL::TS + g * 3;
+                ts[0] = Sq; ts[1] = Sv; ts[2] = Sa;
+            }
+            if (lamrec != nullptr && rc >= 0) {
+                const int nrec = Q->nrec;
+                double* o = lamrec + (size_t)e * (nrec * (1 + 3 * ni)) + nrec + (it * 3) * nrec + rc;
+                o[0] = Sq; o[nrec] = Sv; o[2 * nrec] = Sa;
+            }
+            wave_sync();
+            if (tj >= 0) {  // project the rows: G^T
+                double Rq = Sq, Rv = Sv, Ra = Sa;
+#pragma unroll
+                for (int d = 0; d < 6; d++) {
+                    if (d < ndep) {
+                        const double* ts = sl + LL::TS + depb[d] * 3;
+                        Rq += gdep[d] * ts[0]; Rv += gdep[d] * ts[1]; Ra += gdep[d] * ts[2];
+                    }
+                }
+                if (it == lc0) Rq += Kq[0];
+                if (it == lc1) Rq += Kq[1];
+                double* D = rec + Q->c_D + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
+                D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
+            }
+            wave_sync();
+        }
+        Tq = 0.0; Tv = 0.0; Ta = 0.0; Xq = 0.0; Xv = 0.0; Xa = 0.0;
     }
 }
 

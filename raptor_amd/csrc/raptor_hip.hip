@@ -1160,15 +1160,53 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     static_assert(RAPTOR_LEG_MAX_DEPTH <= 24 && RAPTOR_LEG_MAX_BODIES <= 32, "packed path / entry layout");
     for (int g = 0; g < nb; g++)
         for (int d = 0; d < Q.body_depth[g]; d++) Q.path8[g][d >> 3] |= (unsigned long long)Q.path[g][d] << (8 * (d & 7));
-    Q.flat_n = 0;
     for (int t = 0; t < ni; t++)
         for (int r = 0; r < Q.col_nsupp[t]; r++) {
             const int k = Q.col_supp_body[t][r];
             const unsigned ent = (unsigned)k | (unsigned)Q.body_end[k] << 5 | (unsigned)Q.col_supp_slot[t][r] << 11;
             Q.col_pack[t][r >> 2] |= (unsigned long long)(ent | 1u << 12) << (16 * (r & 3));
-            if (Q.flat_n >= 64) throw unsupported_error("legged kernel: more than 64 (actuator, tree joint) pairs");
-            Q.flat[Q.flat_n++] = (int)(ent | (r == Q.col_nsupp[t] - 1 ? 1u << 12 : 0u) | (unsigned)t << 13);
         }
+    {   // the row pass's work list (legged_kernel.h phase F2): columns that share two-driver joints are merged into one group
+        Q.flat_n = 0;
+        std::vector<int> partner(ni, -1);
+        for (int g = 1; g < nb; g++) {
+            const int c0 = Q.body_col[g][0], c1 = Q.body_col[g][1];
+            if (c0 < 0 || c1 < 0) continue;
+            if ((partner[c0] >= 0 && partner[c0] != c1) || (partner[c1] >= 0 && partner[c1] != c0))
+                throw unsupported_error("legged kernel: a driver shared between different closed loops");
+            partner[c0] = c1;
+            partner[c1] = c0;
+        }
+        auto push = [&](unsigned ent) {
+            if (Q.flat_n >= 64) throw unsupported_error("legged kernel: more than 64 (actuator, tree joint) pairs");
+            Q.flat[Q.flat_n++] = (int)ent;
+        };
+        std::vector<char> done(ni, 0);
+        for (int t = 0; t < ni; t++) {
+            if (done[t]) continue;
+            const int t2 = partner[t];
+            const int first = Q.flat_n;
+            const unsigned cols = (unsigned)t << 15 | (unsigned)(t2 >= 0 ? t2 : 15) << 19;
+            for (int g = 1; g < nb; g++) {
+                const int c0 = Q.body_col[g][0], c1 = Q.body_col[g][1];
+                const unsigned base = (unsigned)g | (unsigned)Q.body_end[g] << 5 | cols;
+                if (t2 >= 0 && c0 >= 0 && c1 >= 0 && ((c0 == t && c1 == t2) || (c0 == t2 && c1 == t))) {
+                    if (c0 != t) throw unsupported_error("legged kernel: two-driver joints must list their drivers in one order");
+                    push(base | 2u << 13);                                  // both sets: slot 0 -> column t, slot 1 -> column t2
+                } else {
+                    for (int slot = 0; slot < 2; slot++) {
+                        const int c = Q.body_col[g][slot];
+                        if (c == t) push(base | (unsigned)slot << 11 | 0u << 13);
+                        else if (t2 >= 0 && c == t2) push(base | (unsigned)slot << 11 | 1u << 13);
+                    }
+                }
+            }
+            if (Q.flat_n == first) throw unsupported_error("legged kernel: an independent joint that moves no tree joint");
+            Q.flat[Q.flat_n - 1] |= (int)(1u << 12);
+            done[t] = 1;
+            if (t2 >= 0) done[t2] = 1;
+        }
+    }
     for (int t = 0; t < ni; t++)
         if (Q.col_nsupp[t] == 0) throw unsupported_error("legged kernel: an independent joint that moves no tree joint");
 
