@@ -764,6 +764,21 @@ void launch_copy2(double* d0, const double* s0, size_t n0, double* d1, const dou
 }  // namespace
 
 // bandwidth probe (scripts/bw_probe.py): every workgroup writes one contiguous chunk with 16-byte stores per lane
+// chunk_doubles = -4 (blocks = workgroups, total = blocks * 8192 doubles): grid-stride order -- in every pass workgroup b writes the
+// 4 KB at (pass * gridDim + b) * 4 KB, so the workgroups in flight always write one dense window (the order torch's fill uses)
+__global__ __launch_bounds__(256) void probe_stride_kernel(double* __restrict__ p, const long long total) {
+    for (long long el = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; el < total; el += (long long)gridDim.x * 512)
+        *reinterpret_cast<double2*>(p + el) = make_double2(1.0, 2.0);
+}
+// chunk_doubles = -5: chunked like probe_fill_kernel (64 KB per workgroup) but every lane writes 64 contiguous bytes per pass
+// (four 16-byte stores); -6: the same with 32 bytes per lane
+template <int W>
+__global__ __launch_bounds__(256) void probe_wide_kernel(double* __restrict__ p) {
+    double* dst = p + (long long)blockIdx.x * 8192;
+    for (int el = threadIdx.x * 2 * W; el < 8192; el += 512 * W)
+#pragma unroll
+        for (int k = 0; k < W; k++) *reinterpret_cast<double2*>(dst + el + 2 * k) = make_double2(1.0, 2.0);
+}
 __global__ __launch_bounds__(256) void probe_fill_kernel(double* __restrict__ p, const long long chunk) {
     double* dst = p + (long long)blockIdx.x * chunk;
     for (long long el = 2 * threadIdx.x; el < chunk; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
@@ -829,6 +844,15 @@ __global__ __launch_bounds__(256) void probe_pattern_kernel(double* __restrict__
 extern "C" {
 
 int raptor_probe_fill(double* d_p, long long blocks, long long chunk_doubles, void* stream) {
+    if (chunk_doubles == -5 || chunk_doubles == -6) {
+        if (chunk_doubles == -5) hipLaunchKernelGGL(probe_wide_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p);
+        else hipLaunchKernelGGL(probe_wide_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p);
+        return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
+    }
+    if (chunk_doubles == -4) {
+        hipLaunchKernelGGL(probe_stride_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, blocks * 8192);
+        return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
+    }
     if (chunk_doubles < 0) {
         hipLaunchKernelGGL(probe_pattern_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, (int)(-1 - chunk_doubles));
         return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;

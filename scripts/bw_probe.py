@@ -31,3 +31,16 @@ for mode, name in ((-1, "expand pattern (3 pieces + 130 scattered rows per workg
                    (-3, "3 pieces per workgroup, customized rows as one contiguous run per workgroup")):
     ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), zs * 7, mode, st))
     print(f"probe {name}: {ms:.3f} ms  {zs*1005*132*8/ms/1e6:.0f} GB/s")
+
+# grid-stride order (dense moving window) with few or many workgroups
+for blocks in (2048, 8192, 32768):
+    ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), blocks, -4, st))
+    print(f"probe grid-stride, {blocks} workgroups x {8192*8//1024} KB total each: {ms:.3f} ms  {blocks*8192*8/ms/1e6:.0f} GB/s")
+
+# wider contiguous runs per lane (64 KB per workgroup)
+for mode, name in ((-6, "32 B per lane"), (-5, "64 B per lane")):
+    blocks = n // 8192
+    ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), blocks, mode, st))
+    print(f"probe {name}, 64 KB chunks: {ms:.3f} ms  {blocks*8192*8/ms/1e6:.0f} GB/s")
+ms = t(lambda: lib.raptor_probe_fill(x.data_ptr(), n // 8192, 8192, st))
+print(f"probe 16 B per lane, 64 KB chunks: {ms:.3f} ms  {(n//8192)*8192*8/ms/1e6:.0f} GB/s")
