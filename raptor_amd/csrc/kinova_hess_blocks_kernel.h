@@ -33,12 +33,18 @@ struct DevHessItems {
     int code[H_WAVES][HB_MAX_ITEMS];
 };
 
-__global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
+// LDS: the sample tables HL_X / HL_MU / HL_WS, then ONE region that holds the wavefronts' hyper-dual virtual-velocity state during the
+// item phase (4 x 24 fields, kinova_hess_kernel.h) and the world-frame tables HL_W / HL_RO of the obstacle phase afterwards; the
+// obstacle sums of the four wavefronts meet in the HL_X area, which nothing reads after the forward kinematics: 72 KB, two
+// workgroups per CU; registers capped at 256 for two wavefronts per SIMD.
+#define HB_SUM HL_X  // [28][64] obstacle sums (after the forward kinematics)
+static_assert(H_PAIRS <= 35, "the obstacle sums fit the HL_X area");
+__global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_hess_blocks_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
     const DevHessItems* __restrict__ items, const double* __restrict__ Z, const double* __restrict__ lambda,
     double* __restrict__ Phi) {
-    __shared__ double lds[HL_ACC + H_WAVES * H_PAIRS * H_CH];
+    __shared__ double lds[HL_ACC];
     constexpr int NV = 7;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,34 +75,6 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
         }
         __syncthreads();
         const bool live = (i0 + lane) < N;
-
-        if (wave == 0 && O > 0 && do_obs) {  // world-frame joint axes / origins and sphere-link poses, lane = sample
-            M3 Rw;
-#pragma unroll
-            for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-            V3 ow = v3(0, 0, 0);
-#pragma unroll 1
-            for (int l = 0; l < NV; l++) {
-                const double* x = lds + HL_X + (l * 5) * H_CH + lane;
-                const M3 A = mul(Rw, M->plR[l]);
-                V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
-                M3 R;
-                SV s;
-                joint_world(M->jtype[l], x[4 * H_CH], x[2 * H_CH], x[3 * H_CH], A, R, o, s);
-                Rw = R;
-                ow = o;
-                double* wv = lds + HL_W + (l * 6) * H_CH + lane;
-                wv[0] = s.a.x; wv[H_CH] = s.a.y; wv[2 * H_CH] = s.a.z;
-                wv[3 * H_CH] = ow.x; wv[4 * H_CH] = ow.y; wv[5 * H_CH] = ow.z;
-                const int slot = S->ro_slot[l];
-                if (slot >= 0) {
-                    double* ro = lds + HL_RO + (slot * 12) * H_CH + lane;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) ro[k * H_CH] = Rw.m[k];
-                    ro[9 * H_CH] = ow.x; ro[10 * H_CH] = ow.y; ro[11 * H_CH] = ow.z;
-                }
-            }
-        }
 
         // ---- torque rows: this wavefront's items ----
         const int cnt = my->count[wave];
@@ -197,7 +175,16 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
             int l = 0;
 #pragma unroll 1
             for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
-            Kin<HD> kh;
+            KinVA<HD> kh;
+            double* ws = lds + HL_WST + wave * 24 * H_CH + lane;  // this lane's column of the wavefront's w state
+#define HPROM(src) \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { \
+        kh.va.c[i_] = promote(src.va.c[i_], (HD*)nullptr); kh.vl.c[i_] = promote(src.vl.c[i_], (HD*)nullptr); \
+        kh.aa.c[i_] = promote(src.aa.c[i_], (HD*)nullptr); kh.al.c[i_] = promote(src.al.c[i_], (HD*)nullptr); \
+    } \
+    { T3<HD> wa_, wl_; \
+      _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { wa_.c[i_] = promote(src.wa.c[i_], (HD*)nullptr); wl_.c[i_] = promote(src.wl.c[i_], (HD*)nullptr); } \
+      w_store(ws, 0, wa_); w_store(ws, 1, wl_); }
             if (pa < pb) {
                 Kin<D1> k1s = promote<D1>(k0);
                 {   // l == pa: first seed
@@ -208,29 +195,60 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
                 }
 #pragma unroll 1
                 for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1s);
-                kh = promote<HD>(k1s);
+                HPROM(k1s)
             } else {
-                kh = promote<HD>(k0);
+                HPROM(k0)
             }
+#undef HPROM
             double phi_ab;
             {   // l == pb: second seed (and the first one too when both sit on this joint)
                 const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
                 const double da = (pa == pb) ? s0 : 0.0, ea = (pa == pb) ? s1 : 0.0, fa = (pa == pb) ? s2 : 0.0;
-                hess_link(M, l, HD{cq, -sq * da, -sq * t0, -cq * da * t0}, sg * HD{sq, cq * da, cq * t0, -sq * da * t0},
-                          HD{HX(l, 0), ea, t1, 0.0}, HD{HX(l, 1), fa, t2, 0.0}, lds[HL_MU + l * H_CH + lane], kh);
-                phi_ab = hess_power_ab(M, l, kh);
+                hess_link_hd(M, l, HD{cq, -sq * da, -sq * t0, -cq * da * t0}, sg * HD{sq, cq * da, cq * t0, -sq * da * t0},
+                             HD{HX(l, 0), ea, t1, 0.0}, HD{HX(l, 1), fa, t2, 0.0}, lds[HL_MU + l * H_CH + lane], kh, ws);
+                phi_ab = hess_power_ab_lds(M, l, kh, ws);
                 l++;
             }
 #pragma unroll 1
             for (; l < NV; l++) {
-                hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh);
-                phi_ab += hess_power_ab(M, l, kh);
+                hess_link_hd(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh, ws);
+                phi_ab += hess_power_ab_lds(M, l, kh, ws);
             }
 #undef HX
 #undef HSG
             if (live) phi[(long long)out * N + i0 + lane] = phi_ab;
         }
-        __syncthreads();  // world-frame tables complete
+        __syncthreads();  // every wavefront is done with its w state: the world-frame tables take the same LDS
+
+        if (wave == 0 && O > 0 && do_obs) {  // world-frame joint axes / origins and sphere-link poses, lane = sample
+            M3 Rw;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            V3 ow = v3(0, 0, 0);
+#pragma unroll 1
+            for (int l = 0; l < NV; l++) {
+                const double* x = lds + HL_X + (l * 5) * H_CH + lane;
+                const M3 A = mul(Rw, M->plR[l]);
+                V3 o = ow + mul(Rw, v3(M->plp[l][0], M->plp[l][1], M->plp[l][2]));
+                M3 R;
+                SV s;
+                joint_world(M->jtype[l], x[4 * H_CH], x[2 * H_CH], x[3 * H_CH], A, R, o, s);
+                Rw = R;
+                ow = o;
+                double* wv = lds + HL_W + (l * 6) * H_CH + lane;
+                wv[0] = s.a.x; wv[H_CH] = s.a.y; wv[2 * H_CH] = s.a.z;
+                wv[3 * H_CH] = ow.x; wv[4 * H_CH] = ow.y; wv[5 * H_CH] = ow.z;
+                const int slot = S->ro_slot[l];
+                if (slot >= 0) {
+                    double* ro = lds + HL_RO + (slot * 12) * H_CH + lane;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) ro[k * H_CH] = Rw.m[k];
+                    ro[9 * H_CH] = ow.x; ro[10 * H_CH] = ow.y; ro[11 * H_CH] = ow.z;
+                }
+            }
+        }
+
+        __syncthreads();  // world-frame tables complete; nothing reads the sample tables of this pass any more
 
         // ---- obstacle rows: a wavefront per sphere, lane = sample; the four partial sums meet in LDS ----
         {
@@ -244,19 +262,22 @@ __global__ __launch_bounds__(RAPTOR_BLOCK) void kinova_hess_blocks_kernel(
                     hess_sphere_terms(lds, lane, S, boxes, O, sp, wgt, acc);
                 }
             }
-            double* part = lds + HL_ACC + wave * H_PAIRS * H_CH;
+            // the wavefronts add their sums one after the other (a fixed order: deterministic), 14 KB instead of four copies
+#pragma unroll 1
+            for (int w = 0; w < H_WAVES; w++) {
+                if (wave == w) {
 #pragma unroll
-            for (int k = 0; k < H_PAIRS; k++) part[k * H_CH + lane] = acc[k];
+                    for (int k = 0; k < H_PAIRS; k++) {
+                        double* c = lds + HB_SUM + k * H_CH + lane;
+                        *c = (w == 0) ? acc[k] : *c + acc[k];
+                    }
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
         for (int idx = tid; idx < H_PAIRS * H_CH; idx += RAPTOR_BLOCK) {
             const int s = idx & (H_CH - 1), k = idx >> 6;
-            if (do_obs && i0 + s < N) {
-                double v = 0.0;
-#pragma unroll
-                for (int w = 0; w < H_WAVES; w++) v += lds[HL_ACC + w * H_PAIRS * H_CH + idx];
-                phi[(long long)(HB_OBS + k) * N + i0 + s] = v;
-            }
+            if (do_obs && i0 + s < N) phi[(long long)(HB_OBS + k) * N + i0 + s] = lds[HB_SUM + idx];
         }
         __syncthreads();  // the sample tables are rewritten by the next pass
     }
