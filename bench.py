@@ -129,7 +129,7 @@ class Digit:
     batch = 4096
     bytes_per_se = None                   # 8 (rows / N) (n + 1) over the expand kernel's rows (torque, joint limits, contact, customized)
     flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
-    kernels = ["digit_loops_kernel<knee,toe> + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
+    kernels = ["digit_loops_both_kernel (knee + toe) + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
                "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
                "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
     pmc_keys = ["legged_core_kernel<32, true>", "legged_expand_kernel"]

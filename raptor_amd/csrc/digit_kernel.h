@@ -273,18 +273,16 @@ struct LoopSolver {
 #define DIGIT_LOOPS_OCC 1
 #endif
 template <bool TOE>
-__global__ __launch_bounds__(64, DIGIT_LOOPS_OCC) void digit_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
-                                                         const double* __restrict__ basis, const int n,
-                                                         const double* __restrict__ Z, const long long total,
-                                                         double* __restrict__ loops, int* __restrict__ status,
-                                                         int* __restrict__ iterations) {
+RD void digit_loops_body(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D, const double* __restrict__ basis, const int n,
+                         const double* __restrict__ Z, const long long total, const int blk, double* __restrict__ loops,
+                         int* __restrict__ status, int* __restrict__ iterations) {
     constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NS = NX * (NX + 1) / 2,
                   NT = NX * (NX + 1) * (NX + 2) / 6;
     // a wavefront works on ONE leg (blockIdx parity), so the loop's constants -- placements, end points, initial-guess tables -- sit
     // behind a uniform pointer and come through scalar loads into SGPR operands; with the leg taken from the lane index they were
     // ~180 vector loads (and 41 waits) in every Newton step
-    const int leg = (int)(blockIdx.x & 1);
-    const long long e = (long long)(blockIdx.x >> 1) * 64 + threadIdx.x;
+    const int leg = blk & 1;
+    const long long e = (long long)(blk >> 1) * 64 + threadIdx.x;
     if (e >= total) return;
     const int N = T->N;
     const int i = (int)(e % N);
@@ -442,6 +440,25 @@ __global__ __launch_bounds__(64, DIGIT_LOOPS_OCC) void digit_loops_kernel(const 
     }
 }
 
+
+template <bool TOE>
+__global__ __launch_bounds__(64, DIGIT_LOOPS_OCC) void digit_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+                                                         const double* __restrict__ basis, const int n,
+                                                         const double* __restrict__ Z, const long long total,
+                                                         double* __restrict__ loops, int* __restrict__ status,
+                                                         int* __restrict__ iterations) {
+    digit_loops_body<TOE>(T, D, basis, n, Z, total, (int)blockIdx.x, loops, status, iterations);
+}
+// Knee and toe loops in ONE launch (they are independent): the first `toe_blocks` workgroups take the toe loops, the rest the knee
+// loops.  For a single problem the two kinds then run side by side instead of one launch after the other.
+__global__ __launch_bounds__(64, DIGIT_LOOPS_OCC) void digit_loops_both_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+                                                              const double* __restrict__ basis, const int n,
+                                                              const double* __restrict__ Z, const long long total, const int toe_blocks,
+                                                              double* __restrict__ loops, int* __restrict__ status,
+                                                              int* __restrict__ iterations) {
+    if ((int)blockIdx.x < toe_blocks) digit_loops_body<true>(T, D, basis, n, Z, total, (int)blockIdx.x, loops, status, iterations);
+    else digit_loops_body<false>(T, D, basis, n, Z, total, (int)blockIdx.x - toe_blocks, loops, status, iterations);
+}
 
 // The multipliers of the closure rows, ConstrainedInverseDynamics::lambda(i) / plambda_pz(i) rows 0 .. 17
 // (KinematicsDynamics/src/ConstrainedInverseDynamics.cpp:154, 169-171).  The reference solves J_dep^T lambda = tau_dep with the

@@ -633,10 +633,9 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     if (p.has_digit) {  // closed loops first: one lane per (sample-eval, leg), knee and toe loops in separate launches
         p.s_loops.ensure((size_t)E * p.hleg.nrec * DIGIT_REC);
         const unsigned lgrid = 2 * (unsigned)((E + 63) / 64);  // a wavefront per (64 sample-evals, leg)
-        hipLaunchKernelGGL((digit_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, E, p.s_loops.p, p.cur_status, p.cur_iterations);
-        hipLaunchKernelGGL((digit_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
-                           p.layout.n, dZ, E, p.s_loops.p, p.cur_status, p.cur_iterations);
+        // knee and toe loops side by side in one launch (measured: 2.426 -> 2.398 ms per Digit step, 211 -> 200 us for one problem)
+        hipLaunchKernelGGL(digit_loops_both_kernel, dim3(2 * lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_basis.p,
+                           p.layout.n, dZ, E, (int)lgrid, p.s_loops.p, p.cur_status, p.cur_iterations);
         HIP_CHECK(hipGetLastError());
         d_loops = p.s_loops.p;
     }
