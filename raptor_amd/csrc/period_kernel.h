@@ -164,6 +164,13 @@ __global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* _
     }
 }
 
+// Phase accounting: -DPER_STOP=k ends the kernel after phase k with a checksum of the whole LDS image (measurement builds only).
+#ifdef PER_STOP
+#define PER_PHASE_END(k) if (PER_STOP == (k)) { double c_ = 0.0; for (int k_ = tid; k_ < PL_TOTAL; k_ += PL_BLOCK) c_ += lds[k_]; \
+                                               if (JAC != nullptr) JAC[rowbase * n + tid] = c_; return; }
+#else
+#define PER_PHASE_END(k)
+#endif
 template <int NVM, int NDM, bool DERIV>
 __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_kernel(const DevModel* __restrict__ M, const DevTraj* __restrict__ T,
                                                                    const DevLegged* __restrict__ Q, const DevPeriod* __restrict__ P,
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         }
     }
     __syncthreads();
+    PER_PHASE_END(1)
 
     // ---- phase A (wavefront 0): world-frame pose and joint axis (walk from the world down to this joint) ----
     M3 Rw;
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     }
     if (on && lead) lds_put(lds + PL_S + g * 6, s);
     __syncthreads();
+    PER_PHASE_END(2)
 
     if (DERIV && wv == 1 && g < ni) {
         // ---- wavefront 1, lane = direction t: d v-/d q_t of the floating base.  The old stance foot stays planted along the
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     }
     if (!DERIV) return;
     __syncthreads();
+    PER_PHASE_END(3)
 
     // ---- phase C3 (all wavefronts): D1 = A Pfull - H Vq, D2 = -H Pfull, D_t(J_foot v+) = B Pfull.  Lane = row (model joint, then
     // the six foot rows), a wavefront takes every PL_WAVES-th direction; Pfull / Vq reads are LDS broadcasts ----
@@ -577,6 +587,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         }
     }
 
+    PER_PHASE_END(4)
     // ---- phase D: Bernstein weights of the first and last sample, d g5, then the dense rows ----
     if (lead && g < K) {
         const double* b0 = link ? basis2 : basis;                 // the first sample is the next step's in a link
@@ -601,21 +612,24 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         lds[PL_C5 + g] = val;
     }
     __syncthreads();
-    // every thread owns a pair of adjacent columns (classified once) and walks down the rows: 16-byte stores, a row's
-    // pairs contiguous across the lanes, no per-element index arithmetic
+    PER_PHASE_END(5)
+    // a thread owns a pair of adjacent columns (classified once) and every ngr-th row below it: 16-byte stores, a row's
+    // pairs contiguous across the lanes, no per-element index arithmetic.  With n = 132 the 66 pairs alone would leave
+    // three of the four wavefronts idle through 91 dependent iterations, hence the row groups.
     const int ndyn = ni * K;
     double* out = JAC + rowbase * n;
-    const bool pairok2 = ((n & 1) == 0) && ((reinterpret_cast<size_t>(JAC) & 15) == 0) && ((reinterpret_cast<size_t>(JAC2) & 15) == 0);
-    const bool pairok = pairok2;
+    const bool pairok = ((n & 1) == 0) && ((reinterpret_cast<size_t>(JAC) & 15) == 0) && ((reinterpret_cast<size_t>(JAC2) & 15) == 0);
     const int wdt = pairok ? 2 : 1;
     const int ncp = (n + wdt - 1) / wdt;
+    const int ngr = (ncp < PL_BLOCK) ? PL_BLOCK / ncp : 1;
     const double* D1s = lds + PL_D1;
     const double* D2s = lds + PL_D2;
     const double* G2s = lds + PL_G2;
     const double* Hs = lds + PL_H;
     const double* JAs = lds + PL_JA;
     const double sgn = P->sign;
-    for (int cp = tid; cp < ncp; cp += PL_BLOCK) {
+    for (int slot = tid; slot < ncp * ngr; slot += PL_BLOCK) {
+        const int g = slot / ncp, cp = slot - g * ncp;
         const int c0 = cp * wdt;
         int kind[2], t[2], a[2];
         double wn0[2], wn1[2], w00[2], w01[2];
@@ -629,56 +643,60 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
             w00[h] = lds[PL_W + k]; w01[h] = lds[PL_W + 16 + k]; wn0[h] = lds[PL_W + 32 + k]; wn1[h] = lds[PL_W + 48 + k];
         }
         double* o = out + c0;
-#define PUT(v0, v1) { if (pairok) store2_stream(o, v0, v1); else o[0] = v0; o += n; }
-        for (int r = 0; r < nv; r++) {  // pg1_pz (:114-116)
+#define PUT(row, v0, v1) { double* o_ = o + (size_t)(row) * n; if (pairok) store2_stream(o_, v0, v1); else o_[0] = v0; }
+        for (int r = g; r < nv; r += ngr) {  // pg1_pz (:114-116)
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 v[h] = (kind[h] == 0) ? D1s[r * ni + t[h]] * wn0[h] + D2s[r * ni + t[h]] * wn1[h]
                                       : ((kind[h] == 1) ? Hs[r * PL_HS + a[h]] : -JAs[a[h] * nv + r]);
-            PUT(v[0], v[1])
+            PUT(r, v[0], v[1])
         }
-        for (int d = 0; d < nd; d++) {  // pg2_pz (:126-127)
+        o += (size_t)nv * n;
+        for (int d = g; d < nd; d += ngr) {  // pg2_pz (:126-127)
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 v[h] = (kind[h] == 0) ? G2s[d * ni + t[h]] * wn0[h] : ((kind[h] == 1) ? JAs[d * nv + a[h]] : 0.0);
-            PUT(v[0], v[1])
+            PUT(d, v[0], v[1])
         }
-        for (int i = 0; i < ni; i++) {  // pg3_pz (:137; link: -pq_pz(last) rows of the independent joints)
+        o += (size_t)nd * n;
+        for (int i = g; i < ni; i += ngr) {  // pg3_pz (:137; link: -pq_pz(last) rows of the independent joints)
             const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], t2 = link ? i : Q->joint_ind[P->id2[i]];
             const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w00[h] : 0.0) + ((t[h] == t2) ? s2 * wn0[h] : 0.0) : 0.0;
-            PUT(v[0], v[1])
+            PUT(i, v[0], v[1])
         }
-        for (int i = 0; i < ni; i++) {  // pg4_pz (:148; link: -pv_plus_pz rows of the independent joints)
+        o += (size_t)ni * n;
+        for (int i = g; i < ni; i += ngr) {  // pg4_pz (:148; link: -pv_plus_pz rows of the independent joints)
             const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], j2 = link ? Q->ind_joint[i] : P->id2[i];
             const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 v[h] = (kind[h] == 0) ? ((t[h] == t1) ? w01[h] : 0.0) : ((kind[h] == 1 && a[h] == j2) ? s2 : 0.0);
-            PUT(v[0], v[1])
+            PUT(i, v[0], v[1])
         }
-        for (int i = 0; i < 7; i++) {  // pg5_pz (:181-204)
+        o += (size_t)ni * n;
+        for (int i = g; i < 7; i += ngr) {  // pg5_pz (:181-204)
             double v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) v[h] = (kind[h] == 2 && a[h] >= nd - 6) ? lds[PL_C5 + i * 6 + a[h] - (nd - 6)] : 0.0;
-            PUT(v[0], v[1])
+            PUT(i, v[0], v[1])
         }
 #undef PUT
         if (link) {  // pg3_pz2, pg4_pz2: pq_pz(0), pq_d_pz(0) of the next step (same column layout as this step's z)
             double* o2 = JAC2 + (size_t)b * 2 * ni * n + c0;
-            for (int i = 0; i < 2 * ni; i++) {
+            for (int i = g; i < 2 * ni; i += ngr) {
                 const int ti = (i < ni) ? i : i - ni;
                 double v[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) v[h] = (kind[h] == 0 && t[h] == ti) ? ((i < ni) ? w00[h] : w01[h]) : 0.0;
-                if (pairok2) store2_stream(o2, v[0], v[1]); else o2[0] = v[0];
-                o2 += n;
+                double* o_ = o2 + (size_t)i * n;
+                if (pairok) store2_stream(o_, v[0], v[1]); else o_[0] = v[0];
             }
         }
     }
