@@ -136,6 +136,7 @@ struct DevPeriod {
     int joint_lane[RAPTOR_MAX_NV];
     int end[64], depth[64];
     int path[64][RAPTOR_LEG_MAX_DEPTH];       // lanes from the root down to and including this one
+    unsigned long long path8[64][RAPTOR_LEG_MAX_DEPTH / 4];  // the same as bytes, then the model joints of those lanes as bytes
     int old_foot_lane, new_foot_lane;         // stance foot of the step, stance foot after the swap
     double endR[9], endp[3];                  // stance_foot_endT after the swap
     int id1[RAPTOR_LEG_MAX_IND], id2[RAPTOR_LEG_MAX_IND];  // JOINT_MAP as model joints

@@ -46,7 +46,8 @@
 #define PL_E (PL_C5 + 42)                          // [3][3] E = d rpy / d omega at the contact frame; [3][3] A9_ij = m . T_ij;
 #define PL_TMP (PL_E + 27)                         // [3][3] Bm = sum_i T_ij omega+_i   (T_ij = d_rpy_rates(R_c, e_i, e_j))
 #define PL_PATH (PL_TMP + 27)                      // bytes: [nv][2][RAPTOR_LEG_MAX_DEPTH] lanes of this lane's path, their model joints
-#define PL_TOTAL (PL_PATH + NVM * 2 * RAPTOR_LEG_MAX_DEPTH / 8)
+#define PL_IDT (PL_PATH + NVM * 2 * RAPTOR_LEG_MAX_DEPTH / 8)  // ints: [3][16] columns / joint that the reset rows g3, g4 touch
+#define PL_TOTAL (PL_IDT + 24)
 constexpr int period_lds_doubles(int NVM, int NDM) { return PL_TOTAL; }
 
 // directional derivative of rpy_rates(R, w) with respect to R along dR = [ww]x R (w fixed): the second-order part of
@@ -220,10 +221,10 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     const unsigned char* pathOf = reinterpret_cast<unsigned char*>(lds + PL_PATH) + of * 2 * RAPTOR_LEG_MAX_DEPTH;
     double vpl = 0.0, dvj = 0.0;
     if (on && lead) {
-        for (int d = 0; d < depth; d++) {
-            const int k = P->path[gj][d];
-            pathL[d] = (unsigned char)k;
-            pathJ[d] = (unsigned char)P->lane_joint[k];
+        {  // one batch of independent 8-byte loads (the int tables would be a chain of dependent loads per level)
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(pathL);
+#pragma unroll
+            for (int k = 0; k < RAPTOR_LEG_MAX_DEPTH / 4; k++) dst[k] = P->path8[gj][k];
         }
         const double qm = recN[Q->c_q + jnt];
         const double vm = recN[Q->c_v + jnt];
@@ -596,6 +597,12 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         lds[PL_W + 32 + g] = basis[(size_t)((N - 1) * 3) * K + g];      // B_k(t_N-1)
         lds[PL_W + 48 + g] = basis[(size_t)((N - 1) * 3 + 1) * K + g];  // dB_k(t_N-1)
     }
+    if (wv == 1 && g < ni) {  // which columns the reset rows touch: looked up once here, not per row in the store loops
+        int* idt = reinterpret_cast<int*>(lds + PL_IDT);
+        idt[g] = link ? -1 : Q->joint_ind[P->id1[g]];
+        idt[16 + g] = link ? g : Q->joint_ind[P->id2[g]];
+        idt[32 + g] = link ? Q->ind_joint[g] : P->id2[g];
+    }
     if (lead && g < 42) {  // d g5 / d lambda.tail(6)   (:181-204)
         const int r = g / 6, c = g - r * 6;
         const double fz = lt.z, mu = Q->mu, gam = Q->gamma;
@@ -628,6 +635,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
     const double* Hs = lds + PL_H;
     const double* JAs = lds + PL_JA;
     const double sgn = P->sign;
+    const int* idt = reinterpret_cast<const int*>(lds + PL_IDT);
     for (int slot = tid; slot < ncp * ngr; slot += PL_BLOCK) {
         const int g = slot / ncp, cp = slot - g * ncp;
         const int c0 = cp * wdt;
@@ -662,7 +670,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         }
         o += (size_t)nd * n;
         for (int i = g; i < ni; i += ngr) {  // pg3_pz (:137; link: -pq_pz(last) rows of the independent joints)
-            const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], t2 = link ? i : Q->joint_ind[P->id2[i]];
+            const int t1 = idt[i], t2 = idt[16 + i];
             const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(PL_BLOCK, (NVM <= 18 ? 4 : 3)) void legged_period_k
         }
         o += (size_t)ni * n;
         for (int i = g; i < ni; i += ngr) {  // pg4_pz (:148; link: -pv_plus_pz rows of the independent joints)
-            const int t1 = link ? -1 : Q->joint_ind[P->id1[i]], j2 = link ? Q->ind_joint[i] : P->id2[i];
+            const int t1 = idt[i], j2 = idt[32 + i];
             const double s2 = link ? -1.0 : sgn;
             double v[2];
 #pragma unroll

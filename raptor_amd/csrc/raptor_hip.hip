@@ -1392,6 +1392,14 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
             P.end[lane] = nl;
         };
         for (int r : roots) walk(r, -1, 1);
+        static_assert(RAPTOR_LEG_MAX_DEPTH % 4 == 0, "path8 rows are whole 8-byte words");
+        for (int lane = 0; lane < nl; lane++) {
+            unsigned char* b8 = reinterpret_cast<unsigned char*>(P.path8[lane]);
+            for (int t = 0; t < P.depth[lane]; t++) {
+                b8[t] = (unsigned char)P.path[lane][t];
+                b8[RAPTOR_LEG_MAX_DEPTH + t] = (unsigned char)P.lane_joint[P.path[lane][t]];
+            }
+        }
         P.old_foot_lane = P.joint_lane[S.contact_joint_id - 1];
         P.new_foot_lane = P.joint_lane[S.period_contact_joint_id - 1];
         for (int k = 0; k < 9; k++) P.endR[k] = S.period_endR[k];
