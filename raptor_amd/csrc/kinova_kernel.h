@@ -601,31 +601,47 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         const bool split_tail = rem > 0 && rem * ((O + KG - 1) / KG + 2) < O;
         const int lim = split_tail ? full : ns;
         const bool box_in_lds = O <= KBOX_LDS;
-        for (int sp = g; sp < lim; sp += KG) {
+        // two spheres per lane and pass: one set of box constants (uniform scalar loads) serves both, and their two dependent
+        // chains (key, square root, gradient) interleave in the issue slots that one chain leaves empty
+        for (int sp = g; sp < lim; sp += 2 * KG) {
+            const bool two = sp + KG < lim;
+            const int sp2 = two ? sp + KG : sp;
             const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
+            const size_t row2 = rowbase + L.off_obs + (size_t)i * ns + sp2;
             if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
-                if (G != nullptr) G[row] = 0.0;
+                if (G != nullptr) { G[row] = 0.0; G[row2] = 0.0; }
                 if (DERIV)
 #pragma unroll
-                    for (int c = 0; c < NV; c++) srow[sp * NV + c] = 0.0;
+                    for (int c = 0; c < NV; c++) { srow[sp * NV + c] = 0.0; srow[sp2 * NV + c] = 0.0; }
                 continue;
             }
-            const SphereInfo si = sphere_info(lds, se, sp);
-            double bkey = 1e300;
-            int bidx = 0;
+            const SphereInfo si = sphere_info(lds, se, sp), sj = sphere_info(lds, se, sp2);
+            double bkey = 1e300, bkey2 = 1e300;
+            int bidx = 0, bidx2 = 0;
 #pragma unroll 2
             for (int ob = 0; ob < O; ob++) {
-                const double key = box_key(boxes + ob, si.point);
+                const double key = box_key(boxes + ob, si.point), key2 = box_key(boxes + ob, sj.point);
                 if (key < bkey) { bkey = key; bidx = ob; }  // strict: the first minimum wins (BoxCollisionAvoidance.cpp:305-308)
+                if (key2 < bkey2) { bkey2 = key2; bidx2 = ob; }
             }
             const BoxHit hit = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx * KBOX_STRIDE), si.point)
                                           : box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
-            if (G != nullptr) G[row] = hit.dist - si.radius;  // KinovaCustomizedConstraints.cpp:145
+            const BoxHit hit2 = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx2 * KBOX_STRIDE), sj.point)
+                                           : box_hit(reinterpret_cast<const double*>(boxes + bidx2), sj.point);
+            if (G != nullptr) {  // KinovaCustomizedConstraints.cpp:145
+                G[row] = hit.dist - si.radius;
+                if (two) G[row2] = hit2.dist - sj.radius;
+            }
             if (DERIV) {
-                const V3 dw = hit.n * w0;
+                const V3 dw = hit.n * w0, dw2 = hit2.n * w0;
                 const SV Wr = SV{cross(si.point, dw), dw};  // diff . (w x (p - o)) = s_c . [p x diff ; diff]
+                const SV Wr2 = SV{cross(sj.point, dw2), dw2};
 #pragma unroll
-                for (int c = 0; c < NV; c++) srow[sp * NV + c] = (c < si.jid) ? dot(lds_sv(se + KL_S + c * 6), Wr) : 0.0;
+                for (int c = 0; c < NV; c++) {
+                    const SV sc = lds_sv(se + KL_S + c * 6);
+                    srow[sp * NV + c] = (c < si.jid) ? dot(sc, Wr) : 0.0;
+                    if (two) srow[sp2 * NV + c] = (c < sj.jid) ? dot(sc, Wr2) : 0.0;
+                }
             }
         }
         if (split_tail) {
