@@ -30,14 +30,12 @@
 #define K_EPB 32   // sample-evals per 256-lane workgroup
 #define K_WAVES (RAPTOR_BLOCK / 64)
 // LDS layout, in doubles.
-//   header (whole workgroup, staged once): sphere tables and the first KBOX_LDS boxes (what box_hit reads for a winner whose
-//   index differs between lanes; the box loop itself reads boxes through uniform scalar loads)
+//   header (whole workgroup, staged once): the sphere tables.  (The box loop reads boxes through uniform scalar loads; the
+//   winner's box, whose index differs between lanes, comes through the vector L1 -- a copy of the box table in this header was
+//   measured slower once two spheres per lane hide that latency, 0.580 against 0.572 ms.)
 #define KH_SPH 0                       // [sphere][4]: offset x y z, radius
 #define KH_SPI (4 * RAPTOR_MAX_SPHERES) // [sphere] two ints: joint id, pose slot
-#define KH_BOX (5 * RAPTOR_MAX_SPHERES) // [box][KBOX_STRIDE]: R (9), R^T centre (3), half sizes (3)
-#define KBOX_LDS 32
-#define KBOX_STRIDE 18                 // 15 used; 36 dwords apart: sixteen lanes on sixteen different boxes hit disjoint banks
-#define KH_SIZE (KH_BOX + KBOX_LDS * KBOX_STRIDE)
+#define KH_SIZE (5 * RAPTOR_MAX_SPHERES)
 //   then one area per wavefront (8 sample-evals, el = 0..7):
 //     el * KW_E  + KL_S   s_j                     7 x 6
 //     el * KW_E  + KL_RO  R, o of up to 4 sphere-carrying links   4 x 12
@@ -232,9 +230,8 @@ struct BoxHit {
     double dist;  // signed distance (BoxCollisionAvoidance.cpp:300-303)
     V3 n;         // d dist / d point in world axes (zero below the threshold, :359-372)
 };
-// b15 = R (9), R^T centre (3), half sizes (3) of the winning box: the head of a DevBox in HBM or its copy in the LDS header
-template <typename PTR>
-RD BoxHit box_hit(PTR b15, V3 p) {
+// b15 = R (9), R^T centre (3), half sizes (3) of the winning box: the head of a DevBox
+RD BoxHit box_hit(const double* __restrict__ b15, V3 p) {
     double R[9], cl[3], hs[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = b15[k];
@@ -353,18 +350,11 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     double* sx = wbase + KW_X + el * KW_XE;  // IS_j, BtS_j
     double* srow = wbase + KW_X + el * rowlen;
 
-    // ---- stage the sphere tables and the first boxes in the LDS header (one barrier, at the start where the waves are aligned) ----
+    // ---- stage the sphere tables in the LDS header (one barrier, at the start where the waves are aligned) ----
     for (int t = tid; t < ns; t += RAPTOR_BLOCK) {
         double* d = lds + KH_SPH + 4 * t;
         d[0] = S->offset[t][0]; d[1] = S->offset[t][1]; d[2] = S->offset[t][2]; d[3] = S->radius[t];
         reinterpret_cast<int2*>(lds + KH_SPI)[t] = make_int2(S->joint_id[t], S->slot[t]);
-    }
-    {
-        const int nb = O < KBOX_LDS ? O : KBOX_LDS;
-        for (int t = tid; t < nb * 15; t += RAPTOR_BLOCK) {
-            const int ob = t / 15, k = t - ob * 15;
-            lds[KH_BOX + ob * KBOX_STRIDE + k] = reinterpret_cast<const double*>(boxes + ob)[k];
-        }
     }
     __syncthreads();
 
@@ -600,7 +590,6 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         const int full = (ns / KG) * KG, rem = ns - full;
         const bool split_tail = rem > 0 && rem * ((O + KG - 1) / KG + 2) < O;
         const int lim = split_tail ? full : ns;
-        const bool box_in_lds = O <= KBOX_LDS;
         // two spheres per lane and pass: one set of box constants (uniform scalar loads) serves both, and their two dependent
         // chains (key, square root, gradient) interleave in the issue slots that one chain leaves empty
         for (int sp = g; sp < lim; sp += 2 * KG) {
@@ -624,10 +613,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                 if (key < bkey) { bkey = key; bidx = ob; }  // strict: the first minimum wins (BoxCollisionAvoidance.cpp:305-308)
                 if (key2 < bkey2) { bkey2 = key2; bidx2 = ob; }
             }
-            const BoxHit hit = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx * KBOX_STRIDE), si.point)
-                                          : box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
-            const BoxHit hit2 = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx2 * KBOX_STRIDE), sj.point)
-                                           : box_hit(reinterpret_cast<const double*>(boxes + bidx2), sj.point);
+            const BoxHit hit = box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
+            const BoxHit hit2 = box_hit(reinterpret_cast<const double*>(boxes + bidx2), sj.point);
             if (G != nullptr) {  // KinovaCustomizedConstraints.cpp:145
                 G[row] = hit.dist - si.radius;
                 if (two) G[row2] = hit2.dist - sj.radius;
@@ -660,8 +647,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                             if (ok_ < bkey || (ok_ == bkey && oi_ < bidx)) { bkey = ok_; bidx = oi_; } }
                 ARGMIN_STEP(0x141) ARGMIN_STEP(0x4E) ARGMIN_STEP(0xB1)
 #undef ARGMIN_STEP
-                const BoxHit hit = box_in_lds ? box_hit(static_cast<const double*>(lds + KH_BOX + bidx * KBOX_STRIDE), si.point)
-                                              : box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
+                const BoxHit hit = box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
                 if (g == 0 && G != nullptr) G[row] = hit.dist - si.radius;
                 if (DERIV) {  // lane c = column c, with its own joint axis still in registers
                     const V3 dw = hit.n * w0;
