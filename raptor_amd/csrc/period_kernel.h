@@ -78,14 +78,12 @@ RD V3 d_rpy_rates(const M3& R, V3 w, V3 ww) {
 // Closed loops of Digit at q-: one lane per (decision vector, leg).  Writes, for its loop, the closure rows of J, J v+,
 // J^T lambda and their derivatives along the loop's own drivers (the only directions that move the loop).
 template <bool TOE>
-__global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
-                                                                const DevPeriod* __restrict__ P,
-                                                                const double* __restrict__ basis, const int n, const int nv,
-                                                                const int nd, const double* __restrict__ Z,
-                                                                const long long total, const double* __restrict__ loops,
-                                                                double* __restrict__ ploops) {
+RD void digit_period_loops_body(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D, const DevPeriod* __restrict__ P,
+                                const double* __restrict__ basis, const int n, const int nv, const int nd,
+                                const double* __restrict__ Z, const long long total, const long long blk,
+                                const double* __restrict__ loops, double* __restrict__ ploops) {
     constexpr int NY = TOE ? 6 : 3, NX = TOE ? 2 : 1, NCL = TOE ? 2 : 1, NA = TOE ? 3 : 2, NB = 2, NVL = NY + NX;
-    const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long w = blk * 64 + threadIdx.x;
     if (w >= total) return;
     const int leg = (int)(w & 1);
     const long long b = w >> 1;
@@ -163,6 +161,17 @@ __global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* _
             oDJTl[k * NX + x] = s;
         }
     }
+}
+
+// knee and toe loops of both legs in one launch: the first `toe_blocks` workgroups take the toe loops (the longer ones first)
+__global__ __launch_bounds__(64) void digit_period_loops_kernel(const DevTraj* __restrict__ T, const DevDigit* __restrict__ D,
+                                                                const DevPeriod* __restrict__ P,
+                                                                const double* __restrict__ basis, const int n, const int nv,
+                                                                const int nd, const double* __restrict__ Z,
+                                                                const long long total, const int toe_blocks,
+                                                                const double* __restrict__ loops, double* __restrict__ ploops) {
+    if ((int)blockIdx.x < toe_blocks) digit_period_loops_body<true>(T, D, P, basis, n, nv, nd, Z, total, blockIdx.x, loops, ploops);
+    else digit_period_loops_body<false>(T, D, P, basis, n, nv, nd, Z, total, (long long)blockIdx.x - toe_blocks, loops, ploops);
 }
 
 // Phase accounting: -DPER_STOP=k ends the kernel after phase k with a checksum of the whole LDS image (measurement builds only).

@@ -225,8 +225,14 @@ struct raptor_problem {
     bool profiling = false;
     std::vector<hipEvent_t> ev;   // 3 per evaluation: before / after the evaluation kernel (third: reserved)
     size_t ev_used = 0;
+    // small-batch fork (launch_legged): a side stream for the reset-map kernels, events for fork / join (created on first use)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_loops = nullptr, ev_core = nullptr, ev_side = nullptr;
     ~raptor_problem() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_loops, ev_core, ev_side})
+            if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -625,7 +631,8 @@ void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, 
 }
 
 // core kernel (values + compact derivative records), then the streaming expansion into pg_pz
-void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st, double* d_lamrec = nullptr) {
+void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st, double* d_lamrec = nullptr,
+                        hipEvent_t after_loops = nullptr) {
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
     p.s_core.ensure((size_t)E * p.hleg.c_stride);
@@ -639,6 +646,7 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
         HIP_CHECK(hipGetLastError());
         d_loops = p.s_loops.p;
     }
+    if (after_loops) HIP_CHECK(hipEventRecord(after_loops, st));
     const bool wide = p.hleg.nb > 16;
     const int LG = wide ? 32 : 16;
     const int epb = LEG_BLOCK / LG;
@@ -660,18 +668,19 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
 // reset-map block: once per decision vector, from the first and last samples' records of launch_legged_core.
 // next / dZ2 / dJ2 non-null: the multiple-step link form (period_kernel.h)
 void launch_period(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st, int mrows, int roff,
-                   raptor_problem* next, const double* dZ2, double* dJ2) {
+                   raptor_problem* next, const double* dZ2, double* dJ2, hipEvent_t core_done = nullptr) {
+    // core_done (small-batch fork): `st` is the side stream; the loop part below needs the loops kernel only (the caller made `st`
+    // wait for it), the reset-map kernel itself waits for the core kernel's records here
     const double* d_pl = nullptr;
     if (p.has_digit) {
         p.s_ploops.ensure((size_t)B * p.hper.loop_stride);
         const long long total = (long long)B * 2;
         const unsigned lgrid = (unsigned)((total + 63) / 64);
-        hipLaunchKernelGGL((digit_period_loops_kernel<false>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
-                           p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
-        hipLaunchKernelGGL((digit_period_loops_kernel<true>), dim3(lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
-                           p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, p.s_loops.p, p.s_ploops.p);
+        hipLaunchKernelGGL(digit_period_loops_kernel, dim3(2 * lgrid), dim3(64), 0, st, p.d_traj.p, p.d_digit.p, p.d_per.p,
+                           p.d_basis.p, p.layout.n, p.hleg.nv, p.hleg.nd, dZ, total, (int)lgrid, p.s_loops.p, p.s_ploops.p);
         d_pl = p.s_ploops.p;
     }
+    if (core_done) HIP_CHECK(hipStreamWaitEvent(st, core_done, 0));
     const DevTraj* T2 = next ? next->d_traj.p : nullptr;
     const double* basis2 = next ? next->d_basis.p : nullptr;
     const bool small = p.hleg.nv <= 18 && p.hleg.nd <= 6;  // Talos / G1; Digit takes the 36 / 24 instance
@@ -690,11 +699,30 @@ void launch_period(raptor_problem& p, const double* dZ, int B, double* dG, doubl
 
 void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
                    hipEvent_t between) {
-    launch_legged_core(p, dZ, B, dG, jac, st);
-    if (p.period_rows && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
+    const long long E = (long long)B * p.htraj.N;
+    // Small batches (one Ipopt-driven problem): the launches are a chain of latencies on a nearly empty GPU, so the reset-map kernels
+    // go to a side stream -- their loop part beside the core kernel, the block itself beside the expansion (disjoint rows out, the
+    // same records in) -- and join before this call's last launch returns the stream to the caller.
+    static const bool no_fork = std::getenv("RAPTOR_NO_FORK") != nullptr;
+    const bool fork = !no_fork && p.period_rows && jac && B > 0 && E <= 512 && between == nullptr;
+    if (fork) {
+        if (p.side == nullptr) {
+            HIP_CHECK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&p.ev_loops, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&p.ev_core, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&p.ev_side, hipEventDisableTiming));
+        }
+        launch_legged_core(p, dZ, B, dG, jac, st, nullptr, p.ev_loops);
+        HIP_CHECK(hipEventRecord(p.ev_core, st));
+        HIP_CHECK(hipStreamWaitEvent(p.side, p.ev_loops, 0));
+        launch_period(p, dZ, B, dG, dJ, jac, p.side, p.layout.m, p.hper.off, nullptr, nullptr, nullptr, p.ev_core);
+        HIP_CHECK(hipEventRecord(p.ev_side, p.side));
+    } else {
+        launch_legged_core(p, dZ, B, dG, jac, st);
+        if (p.period_rows && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
+    }
     if (between) HIP_CHECK(hipEventRecord(between, st));
     if (!jac || B == 0) return;
-    const long long E = (long long)B * p.htraj.N;
     if (p.layout.n % 2 == 0 && ((size_t)dJ & 15) == 0) {
         if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
         const int ndyn = p.hleg.ni * p.hleg.K;
@@ -712,6 +740,7 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
                            p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, total, dJ);
     }
     HIP_CHECK(hipGetLastError());
+    if (fork) HIP_CHECK(hipStreamWaitEvent(st, p.ev_side, 0));
 }
 
 void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, double* dG, double* dJ, hipStream_t st) {
