@@ -704,7 +704,9 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     // go to a side stream -- their loop part beside the core kernel, the block itself beside the expansion (disjoint rows out, the
     // same records in) -- and join before this call's last launch returns the stream to the caller.
     static const bool no_fork = std::getenv("RAPTOR_NO_FORK") != nullptr;
-    const bool fork = !no_fork && p.period_rows && jac && B > 0 && E <= 512 && between == nullptr;
+    static const long long fork_max = std::getenv("RAPTOR_FORK_MAX") ? std::atoll(std::getenv("RAPTOR_FORK_MAX")) : 512;
+    static const bool fork_forced = std::getenv("RAPTOR_FORK_MAX") != nullptr;  // experiments: also under per-kernel timing
+    const bool fork = !no_fork && p.period_rows && jac && B > 0 && E <= fork_max && (between == nullptr || fork_forced);
     if (fork) {
         if (p.side == nullptr) {
             HIP_CHECK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
