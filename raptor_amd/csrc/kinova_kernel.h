@@ -292,23 +292,32 @@ RD void wave_store_run(double* __restrict__ dst, const double* src, int len, int
     }
     if (((len - head) & 1) && lane == 63) dst[len - 1] = src[len - 1];
 }
-// ... or the rows of pq_pz / pq_d_pz of `cnt` consecutive samples from ia on: w * identity per sample, 49 doubles each
-// (ArmourBezierCurves.cpp:147-151)
-RD void wave_store_diag(double* __restrict__ dst, const double* __restrict__ wsum, int ia, int order, int cnt, int lane) {
+// ... or the rows of pq_pz / pq_d_pz of `cnt` consecutive sample-evals of this wave from its `done`-th on: w * identity per sample,
+// 49 doubles each (ArmourBezierCurves.cpp:147-151).  `w` is the lane's own weight (lane group k holds sample-eval k), fetched across
+// the wave by shuffles: no global load sits between the stores.  Every lane runs every pass (the shuffles need their source lanes).
+RD void wave_store_diag(double* __restrict__ dst, const double w, int done, int cnt, int lane) {
     const int len = cnt * 49;
+    if (len <= 0) return;
     auto value = [&](int t) -> double {
-        const int el = t / 49, r = t - el * 49;
-        return (r % 8 == 0) ? wsum[(ia + el) * 3 + order] : 0.0;
+        const int tt = t < len ? t : len - 1;
+        const int el = tt / 49, r = tt - el * 49;
+        const double ws = __shfl(w, (done + el) * KG, 64);
+        return (r % 8 == 0) ? ws : 0.0;
     };
     const int head = (int)(((size_t)dst >> 3) & 1);
-    if (head && lane == 0 && len > 0) dst[0] = value(0);
+    {
+        const double v0 = value(0), v1 = value(len - 1);
+        if (head && lane == 0) dst[0] = v0;
+        if (((len - head) & 1) && lane == 63) dst[len - 1] = v1;
+    }
     const int pairs = (len - head) >> 1;
     double2* dst2 = reinterpret_cast<double2*>(dst + head);
-    for (int pidx = lane; pidx < pairs; pidx += 64) {
+    for (int base = 0; base < pairs; base += 64) {
+        const int pidx = base + lane;
         const int t = head + 2 * pidx;
-        dst2[pidx] = make_double2(value(t), value(t + 1));
+        const double va = value(t), vb = value(t + 1);
+        if (pidx < pairs) dst2[pidx] = make_double2(va, vb);
     }
-    if (((len - head) & 1) && lane == 63) dst[len - 1] = value(len - 1);
 }
 template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
 
@@ -365,6 +374,35 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     const int i0 = __builtin_amdgcn_readfirstlane(i);
     const long long b0 = ((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
 
+    // ---- every global load of the dynamics phases is issued (and awaited) HERE, before the first store: the vector-memory
+    // counter of gfx9 retires loads and stores in issue order, so a load behind a store waits for that store's round trip to HBM ----
+    const bool live = e < E;
+    const int gl_ = (g < NV) ? g : NV - 1;
+    double pq = 0.0, pqd = 0.0, pqdd = 0.0;
+    if (live) traj_joint(T, basis, Z + b * L.n, i, gl_, pq, pqd, pqdd);
+    int pjt = M->jtype[gl_];
+    double pplR[9], pplp[3], plev[3], pIc[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) pplR[k] = M->plR[gl_][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pplp[k] = M->plp[gl_][k]; plev[k] = M->lever[gl_][k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) pIc[k] = M->Ic[gl_][k];
+    double pmass = M->mass[gl_], parm = M->armature[gl_], pdamp = M->damping[gl_], pfric = M->friction[gl_];
+    int pslot = S->ro_slot[gl_];
+    double pw0 = 1.0, pw1 = 0.0, pw2 = 0.0;
+    if (DERIV && !RECORD && live) { pw0 = wsum[i * 3]; pw1 = wsum[i * 3 + 1]; pw2 = wsum[i * 3 + 2]; }
+#define PIN(x) asm volatile("" : "+v"(x))
+    PIN(pq); PIN(pqd); PIN(pqdd); PIN(pmass); PIN(parm); PIN(pdamp); PIN(pfric); PIN(pw0); PIN(pw1); PIN(pw2);
+#pragma unroll
+    for (int k = 0; k < 9; k++) PIN(pplR[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { PIN(pplp[k]); PIN(plev[k]); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) PIN(pIc[k]);
+    asm volatile("" : "+v"(pjt), "+v"(pslot));
+#undef PIN
+
     if (DERIV && !RECORD) {
         // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43): they depend on the sample index only, so they
         // leave first and drain while the dynamics are computed
@@ -373,8 +411,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         while (done < cntw) {
             const int cnt = (cntw - done < N - ia) ? cntw - done : N - ia;
             const size_t rb = (size_t)bb * L.m;
-            wave_store_diag(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, wsum, ia, 0, cnt, lane);
-            wave_store_diag(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, wsum, ia, 1, cnt, lane);
+            wave_store_diag(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, pw0, done, cnt, lane);
+            wave_store_diag(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, pw1, done, cnt, lane);
             done += cnt;
             bb++;
             ia = 0;
@@ -388,8 +426,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         const int gl = own ? g : NV - 1;
 
         // ---- phase 0: joint g's trajectory value and sincos ----
-        double q, qd, qdd, sq, cq;
-        traj_joint(T, basis, z, i, gl, q, qd, qdd);
+        const double q = pq, qd = pqd, qdd = pqdd;
+        double sq, cq;
         sincos_joint(q, &sq, &cq);
         if (own && G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
             G[rowbase + L.off_q + (size_t)i * NV + g] = q;
@@ -402,7 +440,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         // scan of rigid-transform products gives the world pose of every link in three rounds.  The joint axis is a column
         // of that pose, v_g = sum_{k <= g} s_k qd_k and a_g = -a_grav + sum_{k <= g} (s_k qdd_k + (v_k x s_k) qd_k) are two
         // more scans of 6-vectors ((v_{k-1} x s_k qd_k) = (v_k x s_k) qd_k because s_k x s_k = 0).
-        const int jt = M->jtype[gl];
+        const int jt = pjt;
         const int aj = jt < 0 ? -jt : jt;
         const double sg = jt < 0 ? -1.0 : 1.0;
         XF X;
@@ -410,8 +448,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         {
             M3 P;
 #pragma unroll
-            for (int k = 0; k < 9; k++) P.m[k] = M->plR[gl][k];
-            V3 o = v3(M->plp[gl][0], M->plp[gl][1], M->plp[gl][2]);
+            for (int k = 0; k < 9; k++) P.m[k] = pplR[k];
+            V3 o = v3(pplp[0], pplp[1], pplp[2]);
             joint_world(jt, q, cq, sq, P, X.R, o, s);  // the axis it returns is in the parent's frame: recomputed below
             X.p = o;
             if (!own) {  // lane 7 owns no joint: identity, so that it ends up with link 6's pose (and zero mass below)
@@ -442,7 +480,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         a.l = a.l + v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2]);
         if (own) {
             lds_put(se + KL_S + g * 6, s);
-            const int slot = S->ro_slot[g];
+            const int slot = pslot;
             if (slot >= 0) {
                 double* ro = se + KL_RO + slot * 12;
 #pragma unroll
@@ -459,9 +497,9 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         double Qt[6];
         {
             Inertia Ic;
-            const V3 c = ow + mul(Rw, v3(M->lever[gl][0], M->lever[gl][1], M->lever[gl][2]));
-            rotate_inertia(Rw, M->Ic[gl], Ic);
-            const double m = own ? M->mass[gl] : 0.0;
+            const V3 c = ow + mul(Rw, v3(plev[0], plev[1], plev[2]));
+            rotate_inertia(Rw, pIc, Ic);
+            const double m = own ? pmass : 0.0;
             const double keep = own ? 1.0 : 0.0;
             I.m = m;
             I.hv = c * m;
@@ -511,12 +549,12 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
         if (own && G != nullptr) {
             // InverseDynamics.cpp:115-121 (damping, friction); armature inside pinocchio::rnea (>= 3)
             G[rowbase + L.off_tau + (size_t)i * NV + g] =
-                dot(s, F) + M->armature[g] * qdd + M->damping[g] * qd + M->friction[g] * sign_eps(qd);
+                dot(s, F) + parm * qdd + pdamp * qd + pfric * sign_eps(qd);
         }
         double w0 = 0.0;
         if (DERIV) {
-            w0 = RECORD ? 1.0 : wsum[i * 3];
-            const double w1 = RECORD ? 0.0 : wsum[i * 3 + 1], w2 = RECORD ? 0.0 : wsum[i * 3 + 2];
+            w0 = pw0;
+            const double w1 = pw1, w2 = pw2;
             const SV psi = crm(a, s) + crm(v, sd);
             const SV IS = applyO(I, s);
             const SV IdS = applyO(I, sd);
@@ -556,8 +594,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                             dv = 2.0 * dot(ISj, sd) + dot(BtSj, s);
                             da = dot(ISj, s);
                             if (j == g) {
-                                da += M->armature[g];
-                                dv += M->damping[g];
+                                da += parm;
+                                dv += pdamp;
                             }
                         }
                         rec[j * NV] = dq;
@@ -574,7 +612,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
                         d = dot(lds_sv(se + KL_S + j * 6), p);
                     } else {
                         d = dot(lds_sv(sx + j * 12), gam) + dot(lds_sv(sx + j * 12 + 6), bet);
-                        if (j == g) d += M->armature[g] * w2 + M->damping[g] * w1;
+                        if (j == g) d += parm * w2 + pdamp * w1;
                     }
                     trow[j * NV] = d;
                 }
