@@ -280,7 +280,7 @@ RD SphereInfo sphere_info(const double* hdr, const double* se, int sp) {
     si.point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(t[0], t[1], t[2]));
     return si;
 }
-// Wave-level copy-out: `len` doubles to dst (8-byte aligned), 16 bytes per lane, from a contiguous LDS run ...
+// Wave-level copy-out: `len` doubles to dst (8-byte aligned), 16 bytes per lane, from a contiguous LDS run
 RD void wave_store_run(double* __restrict__ dst, const double* src, int len, int lane) {
     const int head = (int)(((size_t)dst >> 3) & 1);  // 16-byte alignment of the run
     if (head && lane == 0 && len > 0) dst[0] = src[0];
@@ -291,33 +291,6 @@ RD void wave_store_run(double* __restrict__ dst, const double* src, int len, int
         dst2[pidx] = make_double2(src[t], src[t + 1]);
     }
     if (((len - head) & 1) && lane == 63) dst[len - 1] = src[len - 1];
-}
-// ... or the rows of pq_pz / pq_d_pz of `cnt` consecutive sample-evals of this wave from its `done`-th on: w * identity per sample,
-// 49 doubles each (ArmourBezierCurves.cpp:147-151).  `w` is the lane's own weight (lane group k holds sample-eval k), fetched across
-// the wave by shuffles: no global load sits between the stores.  Every lane runs every pass (the shuffles need their source lanes).
-RD void wave_store_diag(double* __restrict__ dst, const double w, int done, int cnt, int lane) {
-    const int len = cnt * 49;
-    if (len <= 0) return;
-    auto value = [&](int t) -> double {
-        const int tt = t < len ? t : len - 1;
-        const int el = tt / 49, r = tt - el * 49;
-        const double ws = __shfl(w, (done + el) * KG, 64);
-        return (r % 8 == 0) ? ws : 0.0;
-    };
-    const int head = (int)(((size_t)dst >> 3) & 1);
-    {
-        const double v0 = value(0), v1 = value(len - 1);
-        if (head && lane == 0) dst[0] = v0;
-        if (((len - head) & 1) && lane == 63) dst[len - 1] = v1;
-    }
-    const int pairs = (len - head) >> 1;
-    double2* dst2 = reinterpret_cast<double2*>(dst + head);
-    for (int base = 0; base < pairs; base += 64) {
-        const int pidx = base + lane;
-        const int t = head + 2 * pidx;
-        const double va = value(t), vb = value(t + 1);
-        if (pidx < pairs) dst2[pidx] = make_double2(va, vb);
-    }
 }
 template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
 
@@ -404,19 +377,30 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
 #undef PIN
 
     if (DERIV && !RECORD) {
-        // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43): they depend on the sample index only, so they
-        // leave first and drain while the dynamics are computed
+        // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43; w * identity per sample, ArmourBezierCurves.cpp:147-151):
+        // they depend on the sample index only, so they leave first and drain while the dynamics are computed.  Their image
+        // [order][sample-eval][49] is laid out in this wave's (still unused) LDS area and streamed like the obstacle rows: no index
+        // arithmetic inside the store loop.
+        double* img = wbase;
+        for (int t = lane; t < 2 * 8 * 49; t += 64) img[t] = 0.0;
+        wave_sync();
+        if (g < NV && live) {
+            img[el * 49 + g * 8] = pw0;
+            img[8 * 49 + el * 49 + g * 8] = pw1;
+        }
+        wave_sync();
         int done = 0, ia = i0;
         long long bb = b0;
         while (done < cntw) {
             const int cnt = (cntw - done < N - ia) ? cntw - done : N - ia;
             const size_t rb = (size_t)bb * L.m;
-            wave_store_diag(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, pw0, done, cnt, lane);
-            wave_store_diag(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, pw1, done, cnt, lane);
+            wave_store_run(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, img + done * 49, cnt * 49, lane);
+            wave_store_run(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, img + 8 * 49 + done * 49, cnt * 49, lane);
             done += cnt;
             bb++;
             ia = 0;
         }
+        wave_sync();  // the area is the sample-evals' own from here on
     }
 
     if (e < E) {
