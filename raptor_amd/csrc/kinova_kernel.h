@@ -27,8 +27,14 @@
 #include "kernels.h"
 
 #define KG 8       // lanes per sample-eval
-#define K_EPB 32   // sample-evals per 256-lane workgroup
-#define K_WAVES (RAPTOR_BLOCK / 64)
+#ifndef KIN_BLOCK
+#define KIN_BLOCK 64   // lanes per workgroup: one wavefront (measured 64 / 128 / 256 / 512 lanes: 0.52 / 0.52 / 0.525 / 0.62 ms; run-to-run noise 1 %)
+#endif
+#ifndef KIN_WGS
+#define KIN_WGS 2      // waves per SIMD asked of the register allocation
+#endif
+#define K_EPB (KIN_BLOCK / KG)   // sample-evals per workgroup
+#define K_WAVES (KIN_BLOCK / 64)
 // LDS layout, in doubles.
 //   header (whole workgroup, staged once): the sphere tables.  (The box loop reads boxes through uniform scalar loads; the
 //   winner's box, whose index differs between lanes, comes through the vector L1 -- a copy of the box table in this header was
@@ -309,7 +315,7 @@ template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp
 #endif
 RD double sv_sum(SV x) { return x.a.x + x.a.y + x.a.z + x.l.x + x.l.y + x.l.z; }
 template <bool DERIV, bool RECORD = false>
-__global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
+__global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes,
     const DevLayout L, const double* __restrict__ Z, const long long E, double* __restrict__ G,
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, 2) void kinova_fused_kernel(
     double* srow = wbase + KW_X + el * rowlen;
 
     // ---- stage the sphere tables in the LDS header (one barrier, at the start where the waves are aligned) ----
-    for (int t = tid; t < ns; t += RAPTOR_BLOCK) {
+    for (int t = tid; t < ns; t += KIN_BLOCK) {
         double* d = lds + KH_SPH + 4 * t;
         d[0] = S->offset[t][0]; d[1] = S->offset[t][1]; d[2] = S->offset[t][2]; d[3] = S->radius[t];
         reinterpret_cast<int2*>(lds + KH_SPI)[t] = make_int2(S->joint_id[t], S->slot[t]);

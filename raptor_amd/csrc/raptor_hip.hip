@@ -514,7 +514,7 @@ void launch_kinova(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         attr_set[DERIV] = true;
     }
     const unsigned grid = (unsigned)((E + K_EPB - 1) / K_EPB);
-    hipLaunchKernelGGL((kinova_fused_kernel<DERIV, RECORD>), dim3(grid), dim3(RAPTOR_BLOCK), lds_bytes, st, p.d_model.p,
+    hipLaunchKernelGGL((kinova_fused_kernel<DERIV, RECORD>), dim3(grid), dim3(KIN_BLOCK), lds_bytes, st, p.d_model.p,
                        p.d_traj.p, p.d_basis.p, p.d_wsum.p, p.d_spheres.p, p.d_boxes.p, p.layout, dZ, E, dG, dJ);
     HIP_CHECK(hipGetLastError());
 }
