@@ -152,6 +152,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const double arm_j = has_joint ? M->armature[jnt] : 0.0, damp_j = has_joint ? M->damping[jnt] : 0.0;
 
     // ---- phase 0: this body's joint value, rates, chain-rule weights towards the independent columns, sincos ----
+    const int flat_pre = DERIV ? Q->flat[tid] : 0;  // phase F2's work list: loaded before any store (in-order vector-memory counter)
     double q = 0.0, qd = 0.0, qdd = 0.0, sq = 0.0, cq = 1.0;
     double w0[3] = {1.0, 0.0, 0.0}, w1[3] = {0.0, 0.0, 0.0};
     if (tj >= 0) {
@@ -312,13 +313,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const V3 pf = v3(Q->p_foot[0], Q->p_foot[1], Q->p_foot[2]);
     // tree-joint torque; ConstrainedInverseDynamics.cpp:131-132 (damping only; armature lives inside pinocchio::rnea >= 3)
     const double tt = has_joint ? dot(s, F) + arm_j * qdd + damp_j * qd : 0.0;
-    if (lamrec != nullptr && rc >= 0) lamrec[(size_t)e * (Q->nrec * (1 + 3 * ni)) + rc] = tt;
-    if (has_joint) {
-        rec[Q->c_q + jnt] = q;
-        rec[Q->c_v + jnt] = qd;
-        rec[Q->c_a + jnt] = qdd;
-        if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);  // ConstrainedJointLimits.cpp:57
-    }
+    // Every table look-up and record load of phases D and E is issued here, before the first store of the kernel: the vector-memory
+    // counter retires loads and stores in issue order, so a load behind a store waits for that store's round trip.
     // an actuator's lane collects, from the lanes of the closed-loop joints it drives, their G = Y1 entry and torque
     const int myslot = (tj >= 0) ? Q->ind_slot[tj] : 0;
     const int ndep = (tj >= 0) ? Q->ind_ndep[tj] : 0;
@@ -336,6 +332,37 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         const double td = __shfl(tt, db, LG);
         gdep[d] = (d < ndep) ? (myslot ? gb_ : ga) : 0.0;
         tdep[d] = (d < ndep) ? td : 0.0;
+    }
+    // (dG^T/dq) tau_tree: an actuator's torque also changes because the loop Jacobian Y1 moves with the drivers
+    double Kq[2] = {0.0, 0.0};
+    if (DERIV && ndep > 0) {  // all twelve loads in flight together (a branch per joint would wait for each pair in turn)
+        double k0[6], k1[6];
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const double* ld = loops + ((size_t)e * Q->nrec + recb[d]) * 10;
+            k0[d] = ld[3 + myslot];
+            k1[d] = ld[4 + myslot];
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            Kq[0] += k0[d] * tdep[d];
+            Kq[1] += k1[d] * tdep[d];
+        }
+    }
+    // the first round of customized rows: table entries before the stores as well
+    const int cs0 = (Q->ncust > 0 && G != nullptr) ? cust_start[i] : 0, cs1 = (Q->ncust > 0 && G != nullptr) ? cust_start[i + 1] : 0;
+    int crow0 = 0;
+    DevCustRow cr0 = {};
+    if (cs0 + g < cs1) {
+        crow0 = cust_list[cs0 + g];
+        cr0 = cust[crow0];
+    }
+    if (lamrec != nullptr && rc >= 0) lamrec[(size_t)e * (Q->nrec * (1 + 3 * ni)) + rc] = tt;
+    if (has_joint) {
+        rec[Q->c_q + jnt] = q;
+        rec[Q->c_v + jnt] = qd;
+        rec[Q->c_a + jnt] = qdd;
+        if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);  // ConstrainedJointLimits.cpp:57
     }
     if (tj >= 0) {
         // actuated torque = G^T tau_tree: own joint plus the closed-loop joints this actuator drives
@@ -426,9 +453,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             for (int k = 0; k < 6; k++) rec[Q->c_sf + k] = X[k];
         }
         if (G != nullptr) {  // this sample's rows, one per lane and round: the table look-ups of a row are a chain of dependent loads
-            for (int rr = cust_start[i] + g; rr < cust_start[i + 1]; rr += LG) {
-                const int row = cust_list[rr];
-                const DevCustRow cr = cust[row];
+            for (int rr = cs0 + g; rr < cs1; rr += LG) {
+                const bool first = rr == cs0 + g;
+                const int row = first ? crow0 : cust_list[rr];
+                const DevCustRow cr = first ? cr0 : cust[row];
                 double xa = 0.0, xb = 0.0;
 #pragma unroll
                 for (int k = 0; k < 12; k++) {
@@ -462,22 +490,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             double* vv = sl + LL::V + g * LEG_VEC;
             lds_put(vv, s); lds_put(vv + 6, sd); lds_put(vv + 12, psi);
             lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
-        }
-    }
-    // (dG^T/dq) tau_tree: an actuator's torque also changes because the loop Jacobian Y1 moves with the drivers
-    double Kq[2] = {0.0, 0.0};
-    if (ndep > 0) {  // all twelve loads in flight together (a branch per joint would wait for each pair in turn)
-        double k0[6], k1[6];
-#pragma unroll
-        for (int d = 0; d < 6; d++) {
-            const double* ld = loops + ((size_t)e * Q->nrec + recb[d]) * 10;
-            k0[d] = ld[3 + myslot];
-            k1[d] = ld[4 + myslot];
-        }
-#pragma unroll
-        for (int d = 0; d < 6; d++) {
-            Kq[0] += k0[d] * tdep[d];
-            Kq[1] += k1[d] * tdep[d];
         }
     }
     const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // accumulator sets: the pair quantities (five dot products, 18 doubles from LDS) of a shared joint do not depend on the column
     // and are formed once (42 -> 30 steps for Digit).  Entry: body | end << 5 | slot << 11 | last << 12 | mode << 13 | column of set 0
     // << 15 | column of set 1 << 19 (15: none); mode 0 / 1: into set 0 / 1 with weight slot `slot`, 2: into both, slot 0 / slot 1.
-    const int flat = Q->flat[tid];
+    const int flat = flat_pre;  // loaded in phase 0
     const int nflat = Q->flat_n;
     double Tq = 0.0, Tv = 0.0, Ta = 0.0, Xq = 0.0, Xv = 0.0, Xa = 0.0;
 #pragma unroll 1
