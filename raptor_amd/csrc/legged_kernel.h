@@ -144,7 +144,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int tj = has_joint ? Q->body_traj[gb] : -1;
     const int rc = has_joint ? Q->body_rec[gb] : -1;
     const int gend = has_body ? Q->body_end[gb] : LG;
-    const double* lr = (rc >= 0) ? loops + ((size_t)e * Q->nrec + rc) * 10 : nullptr;
     // tables this lane walks later, fetched now: inside the loops a dependent global load per step is what the two wavefronts
     // per SIMD cannot hide
     unsigned long long pcur = Q->path8[gb][0];
@@ -155,23 +154,70 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int flat_pre = DERIV ? Q->flat[tid] : 0;  // phase F2's work list: loaded before any store (in-order vector-memory counter)
     double q = 0.0, qd = 0.0, qdd = 0.0, sq = 0.0, cq = 1.0;
     double w0[3] = {1.0, 0.0, 0.0}, w1[3] = {0.0, 0.0, 0.0};
-    if (tj >= 0) {
-        traj_joint(T, basis, z, i, tj, q, qd, qdd);
-    } else if (rc >= 0) {
-        // closed-loop joint: theta = y(x), theta' = Y1 x', theta'' = Y1 x'' + x'^T Y2 x'   (digit_kernel.h records)
-        const int ca = Q->body_col[gb][0], cb = Q->body_col[gb][1];
-        double xa, xda, xdda, xb = 0.0, xdb = 0.0, xddb = 0.0;
-        traj_joint(T, basis, z, i, ca, xa, xda, xdda);
-        if (cb >= 0) traj_joint(T, basis, z, i, cb, xb, xdb, xddb);
-        q = lr[0];
-        qd = lr[1] * xda + lr[2] * xdb;
-        qdd = lr[1] * xdda + lr[2] * xddb + lr[3] * xda * xda + 2.0 * lr[4] * xda * xdb + lr[5] * xdb * xdb;
-        w0[0] = lr[1];
-        w0[1] = 2.0 * (lr[3] * xda + lr[4] * xdb);
-        w0[2] = lr[3] * xdda + lr[4] * xddb + lr[6] * xda * xda + 2.0 * lr[7] * xda * xdb + lr[8] * xdb * xdb;
-        w1[0] = lr[2];
-        w1[1] = 2.0 * (lr[4] * xda + lr[5] * xdb);
-        w1[2] = lr[4] * xdda + lr[5] * xddb + lr[7] * xda * xda + 2.0 * lr[8] * xda * xdb + lr[9] * xdb * xdb;
+    {
+        // Every lane evaluates (up to) two trajectory columns -- an actuator its own, a closed-loop joint its loop's drivers -- with
+        // all coefficient, basis and loop-record loads in flight together: the three traj_joint calls this replaces sat under divergent
+        // branches, each a loop of K load -> wait -> FMA steps (~18 dependent round trips at the start of every wavefront).
+        const int ca = (tj >= 0) ? tj : ((rc >= 0) ? Q->body_col[gb][0] : -1);
+        const int cb = (tj < 0 && rc >= 0) ? Q->body_col[gb][1] : -1;
+        double xa = 0.0, xda = 0.0, xdda = 0.0, xb = 0.0, xdb = 0.0, xddb = 0.0;
+        const int K = T->K;
+        double lrv[10];
+        {
+            const double* lp = loops != nullptr ? loops + ((size_t)e * Q->nrec + (rc >= 0 ? rc : 0)) * 10 : nullptr;
+#pragma unroll
+            for (int k = 0; k < 10; k++) lrv[k] = (lp != nullptr) ? lp[k] : 0.0;
+        }
+        if (T->type == RAPTOR_TRAJ_BEZIER && K <= 8) {  // (uniform)
+            const int ja = ca >= 0 ? ca : 0, jb = cb >= 0 ? cb : 0;
+            const double* B0 = basis + (size_t)(i * 3) * K;
+            double za[8], zb[8], b0[8], b1[8], b2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int kk = k < K ? k : 0;
+                za[k] = z[ja * K + kk];  // column-major reshape (Utils.h:142-146)
+                zb[k] = z[jb * K + kk];
+                b0[k] = B0[kk];
+                b1[k] = B0[K + kk];
+                b2[k] = B0[2 * K + kk];
+            }
+            double fa[3] = {0.0, 0.0, 0.0}, fb[3] = {0.0, 0.0, 0.0};
+            if (T->nfixed > 0) {  // rows pinned by the constrained initial state (BezierCurves.cpp:84-96): table after the basis
+                const int Nact = T->Nact;
+                const double* fx = basis + (size_t)T->N * 3 * K + (size_t)(i * 3) * Nact;
+#pragma unroll
+                for (int o = 0; o < 3; o++) { fa[o] = fx[o * Nact + ja]; fb[o] = fx[o * Nact + jb]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < K) {
+                    xa += za[k] * b0[k]; xda += za[k] * b1[k]; xdda += za[k] * b2[k];
+                    xb += zb[k] * b0[k]; xdb += zb[k] * b1[k]; xddb += zb[k] * b2[k];
+                }
+            }
+            xa += fa[0]; xda += fa[1]; xdda += fa[2];
+            xb += fb[0]; xdb += fb[1]; xddb += fb[2];
+            if (ca < 0) { xa = 0.0; xda = 0.0; xdda = 0.0; }
+            if (cb < 0) { xb = 0.0; xdb = 0.0; xddb = 0.0; }
+        } else {
+            if (ca >= 0) traj_joint(T, basis, z, i, ca, xa, xda, xdda);
+            if (cb >= 0) traj_joint(T, basis, z, i, cb, xb, xdb, xddb);
+        }
+        if (tj >= 0) {
+            q = xa; qd = xda; qdd = xdda;
+        } else if (rc >= 0) {
+            // closed-loop joint: theta = y(x), theta' = Y1 x', theta'' = Y1 x'' + x'^T Y2 x'   (digit_kernel.h records)
+            const double* lr = lrv;
+            q = lr[0];
+            qd = lr[1] * xda + lr[2] * xdb;
+            qdd = lr[1] * xdda + lr[2] * xddb + lr[3] * xda * xda + 2.0 * lr[4] * xda * xdb + lr[5] * xdb * xdb;
+            w0[0] = lr[1];
+            w0[1] = 2.0 * (lr[3] * xda + lr[4] * xdb);
+            w0[2] = lr[3] * xdda + lr[4] * xddb + lr[6] * xda * xda + 2.0 * lr[7] * xda * xdb + lr[8] * xdb * xdb;
+            w1[0] = lr[2];
+            w1[1] = 2.0 * (lr[4] * xda + lr[5] * xdb);
+            w1[2] = lr[4] * xdda + lr[5] * xddb + lr[7] * xda * xda + 2.0 * lr[8] * xda * xdb + lr[9] * xdb * xdb;
+        }
     }
     if (has_joint) {
         // local transform across this joint in the direction of the walk (foot -> this body), so that the walk below is
@@ -316,15 +362,23 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // Every table look-up and record load of phases D and E is issued here, before the first store of the kernel: the vector-memory
     // counter retires loads and stores in issue order, so a load behind a store waits for that store's round trip.
     // an actuator's lane collects, from the lanes of the closed-loop joints it drives, their G = Y1 entry and torque
-    const int myslot = (tj >= 0) ? Q->ind_slot[tj] : 0;
-    const int ndep = (tj >= 0) ? Q->ind_ndep[tj] : 0;
-    double gdep[6], tdep[6];
+    // (unconditional loads from valid addresses, selected afterwards: a load under `d < ndep` becomes a branch per entry and the
+    // twelve look-ups a chain of twelve waits)
+    const int tjc = tj >= 0 ? tj : 0;
+    const int myslot_ld = Q->ind_slot[tjc], ndep_ld = Q->ind_ndep[tjc];
     int depb[6];  // bodies of the closed-loop joints this actuator drives
 #pragma unroll
-    for (int d = 0; d < 6; d++) depb[d] = (d < ndep) ? Q->ind_dep_body[tj][d] : 0;
+    for (int d = 0; d < 6; d++) depb[d] = Q->ind_dep_body[tjc][d];
+    const int myslot = (tj >= 0) ? myslot_ld : 0;
+    const int ndep = (tj >= 0) ? ndep_ld : 0;
+    double gdep[6], tdep[6];
+#pragma unroll
+    for (int d = 0; d < 6; d++) depb[d] = (d < ndep) ? (depb[d] & (RAPTOR_LEG_MAX_BODIES - 1)) : 0;
     int recb[6];  // their records in the loop buffer (entry 0 beyond ndep: a valid address, weighted by zero below)
 #pragma unroll
-    for (int d = 0; d < 6; d++) recb[d] = (d < ndep) ? Q->body_rec[depb[d]] : 0;
+    for (int d = 0; d < 6; d++) recb[d] = Q->body_rec[depb[d]];
+#pragma unroll
+    for (int d = 0; d < 6; d++) recb[d] = (d < ndep) ? recb[d] : 0;
 #pragma unroll
     for (int d = 0; d < 6; d++) {
         const int db = depb[d];
