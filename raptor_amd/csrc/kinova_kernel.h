@@ -382,33 +382,6 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     asm volatile("" : "+v"(pjt), "+v"(pslot));
 #undef PIN
 
-    if (DERIV && !RECORD) {
-        // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43; w * identity per sample, ArmourBezierCurves.cpp:147-151):
-        // they depend on the sample index only, so they leave first and drain while the dynamics are computed.  Their image
-        // [order][sample-eval][49] is laid out in this wave's (still unused) LDS area and streamed like the obstacle rows: no index
-        // arithmetic inside the store loop.
-        double* img = wbase;
-        for (int t = lane; t < 2 * 8 * 49; t += 64) img[t] = 0.0;
-        wave_sync();
-        if (g < NV && live) {
-            img[el * 49 + g * 8] = pw0;
-            img[8 * 49 + el * 49 + g * 8] = pw1;
-        }
-        wave_sync();
-        int done = 0, ia = i0;
-        long long bb = b0;
-        while (done < cntw) {
-            const int cnt = (cntw - done < N - ia) ? cntw - done : N - ia;
-            const size_t rb = (size_t)bb * L.m;
-            wave_store_run(JAC + (rb + L.off_q + (size_t)ia * NV) * NV, img + done * 49, cnt * 49, lane);
-            wave_store_run(JAC + (rb + L.off_qd + (size_t)ia * NV) * NV, img + 8 * 49 + done * 49, cnt * 49, lane);
-            done += cnt;
-            bb++;
-            ia = 0;
-        }
-        wave_sync();  // the area is the sample-evals' own from here on
-    }
-
     if (e < E) {
         const double* z = Z + b * L.n;  // L.n == 7 for ArmourBezierCurves
         const size_t rowbase = (size_t)b * L.m;
@@ -422,6 +395,18 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         if (own && G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
             G[rowbase + L.off_q + (size_t)i * NV + g] = q;
             G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;
+        }
+        if (DERIV && !RECORD && own) {
+            // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43; w * identity per sample, ArmourBezierCurves.cpp:147-151)
+            // straight from registers, like the torque rows of phase E: lane g writes column g of the 7 x 7 block, the 7 lanes of a
+            // group one 56-byte row per store
+            double* qrow = JAC + (rowbase + L.off_q + (size_t)i * NV) * NV + g;
+            double* vrow = JAC + (rowbase + L.off_qd + (size_t)i * NV) * NV + g;
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                qrow[j * NV] = (j == g) ? pw0 : 0.0;
+                vrow[j * NV] = (j == g) ? pw1 : 0.0;
+            }
         }
         KIN_PHASE_END(1, q + qd + qdd + sq + cq)
 
