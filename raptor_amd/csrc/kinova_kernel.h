@@ -371,8 +371,12 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     int pslot = S->ro_slot[gl_];
     double pw0 = 1.0, pw1 = 0.0, pw2 = 0.0;
     if (DERIV && !RECORD && live) { pw0 = wsum[i * 3]; pw1 = wsum[i * 3 + 1]; pw2 = wsum[i * 3 + 2]; }
+    // the terms of tau and of its diagonal Jacobian entry that involve only this lane's own joint: formed now, so that qd, qdd and
+    // the three joint constants do not stay live into the register peak of phase D (InverseDynamics.cpp:115-121)
+    double ptau_own = parm * pqdd + pdamp * pqd + pfric * sign_eps(pqd);
+    double pdiag_own = parm * pw2 + pdamp * pw1;
 #define PIN(x) asm volatile("" : "+v"(x))
-    PIN(pq); PIN(pqd); PIN(pqdd); PIN(pmass); PIN(parm); PIN(pdamp); PIN(pfric); PIN(pw0); PIN(pw1); PIN(pw2);
+    PIN(pq); PIN(pqd); PIN(pqdd); PIN(pmass); PIN(parm); PIN(pdamp); PIN(ptau_own); PIN(pdiag_own); PIN(pw0); PIN(pw1); PIN(pw2);
 #pragma unroll
     for (int k = 0; k < 9; k++) PIN(pplR[k]);
 #pragma unroll
@@ -524,25 +528,27 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         if (own && G != nullptr) {
             // InverseDynamics.cpp:115-121 (damping, friction); armature inside pinocchio::rnea (>= 3)
             G[rowbase + L.off_tau + (size_t)i * NV + g] =
-                dot(s, F) + parm * qdd + pdamp * qd + pfric * sign_eps(qd);
+                dot(s, F) + ptau_own;
         }
         double w0 = 0.0;
         if (DERIV) {
             w0 = pw0;
             const double w1 = pw1, w2 = pw2;
+            // staged so that few of the 6-vectors are live together (this is the kernel's register peak):
+            //   p = IS w2 + cv w1 + cq w0,  cv = 2 I sd + Q s + s x* H,  cq = I psi + Q sd + sd x* H + s x* F,  BtS = Q s - s x* H
             const SV psi = crm(a, s) + crm(v, sd);
             const SV IS = applyO(I, s);
-            const SV IdS = applyO(I, sd);
-            const SV Ipsi = applyO(I, psi);
-            const SV QS = applyQ(Qt, H.l, s);
-            const SV QdS = applyQ(Qt, H.l, sd);
-            const SV HS = crf(s, H);
-            const SV HdS = crf(sd, H);
-            const SV cF = crf(s, F);
-            const SV BtS = QS - HS;
-            const SV cv = IdS * 2.0 + QS + HS;
-            const SV cq_ = Ipsi + QdS + HdS + cF;
-            const SV p = IS * w2 + cv * w1 + cq_ * w0;
+            SV p = IS * w2;
+            SV cv, cq_, BtS;
+            {
+                const SV QS = applyQ(Qt, H.l, s);
+                const SV HS = crf(s, H);
+                BtS = QS - HS;
+                cv = applyO(I, sd) * 2.0 + QS + HS;
+            }
+            p = p + cv * w1;
+            cq_ = applyO(I, psi) + applyQ(Qt, H.l, sd) + crf(sd, H) + crf(s, F);
+            p = p + cq_ * w0;
             const SV gam = s * w2 + sd * (2.0 * w1) + psi * w0;
             const SV bet = s * w1 + sd * w0;
             if (own) {
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
                         d = dot(lds_sv(se + KL_S + j * 6), p);
                     } else {
                         d = dot(lds_sv(sx + j * 12), gam) + dot(lds_sv(sx + j * 12 + 6), bet);
-                        if (j == g) d += parm * w2 + pdamp * w1;
+                        if (j == g) d += pdiag_own;
                     }
                     trow[j * NV] = d;
                 }
