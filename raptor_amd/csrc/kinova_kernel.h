@@ -346,12 +346,17 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     }
     __syncthreads();
 
-    const int i = (int)(e % N);
-    const long long b = e / N;
+    // sample index / decision vector of this lane's sample-eval: ONE scalar 64-bit division per wavefront (its first sample-eval),
+    // then a wrap per lane -- a per-lane e / N, e % N is ~100 VALU instructions of the wave's 3400
+    const long long ew0u = ((long long)__builtin_amdgcn_readfirstlane((int)(ew0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ew0);
+    const long long b0 = ew0u / N;
+    const int i0 = (int)(ew0u - b0 * N);
+    int i = i0 + el;
+    int wrap = 0;
+    while (i >= N) { i -= N; wrap++; }  // (N >= 8 in every configuration of the reference: at most once)
+    const long long b = b0 + wrap;
     // the run structure of this wave's sample-evals (wave-uniform): they start at sample i0 of decision vector b0
     const int cntw = (int)((E - ew0 < 8) ? ((E - ew0 > 0) ? E - ew0 : 0) : 8);
-    const int i0 = __builtin_amdgcn_readfirstlane(i);
-    const long long b0 = ((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
 
     // ---- every global load of the dynamics phases is issued (and awaited) HERE, before the first store: the vector-memory
     // counter of gfx9 retires loads and stores in issue order, so a load behind a store waits for that store's round trip to HBM ----
