@@ -128,11 +128,16 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int eg = tid / LG;
     // a lane group past the end repeats the last sample-eval (same values to the same addresses): every lane of the wavefront
     // stays active, which the packed table of phase F2 (an entry per lane, read with v_readlane) relies on
-    const long long e = min((long long)blockIdx.x * EPB + eg, E - 1);
+    const long long e0 = (long long)blockIdx.x * EPB;  // (uniform; < E by the launch grid)
+    const long long e = min(e0 + eg, E - 1);
     double* sl = lds + eg * LL::STRIDE;
     const int N = T->N;
-    const int i = (int)(e % N);
-    const long long b = e / N;
+    // one 64-bit division per wavefront (its first sample-eval), then a wrap per lane group: a per-lane e / N, e % N is ~150 VALU
+    const long long b0 = e0 / N;
+    int i = (int)(e0 - b0 * N) + (int)(e - e0);
+    int wrap = 0;
+    while (i >= N) { i -= N; wrap++; }
+    const long long b = b0 + wrap;
     const double* z = Z + b * L.n;
     const size_t rowbase = (size_t)b * L.m;
     double* rec = core + (size_t)e * Q->c_stride;
