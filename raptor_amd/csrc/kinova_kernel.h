@@ -31,7 +31,7 @@
 #define KIN_BLOCK 64   // lanes per workgroup: one wavefront (measured 64 / 128 / 256 / 512 lanes: 0.52 / 0.52 / 0.525 / 0.62 ms; run-to-run noise 1 %)
 #endif
 #ifndef KIN_WGS
-#define KIN_WGS 2      // waves per SIMD asked of the register allocation
+#define KIN_WGS 3      // waves per SIMD asked of the register allocation (168 VGPRs; LDS lets 11 one-wavefront workgroups share a CU)
 #endif
 #define K_EPB (KIN_BLOCK / KG)   // sample-evals per workgroup
 #define K_WAVES (KIN_BLOCK / 64)
@@ -309,7 +309,7 @@ template <int CTRL> RD int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp
 // Phase accounting: a build with -DKIN_STOP=k ends the kernel after phase k, storing a checksum of what is live
 // there so that the phase is not optimised away.  Measurement builds only (scripts/kinova_phases.sh); never defined in the product.
 #ifdef KIN_STOP
-#define KIN_PHASE_END(k, expr) if (KIN_STOP == (k)) { if (own && G != nullptr) G[rowbase + L.off_tau + (size_t)i * NV + g] = (expr); return; }
+#define KIN_PHASE_END(k, expr) if (KIN_STOP == (k)) { if (own && G != nullptr) Gb[ro + L.off_tau + i * NV + g] = (expr); return; }
 #else
 #define KIN_PHASE_END(k, expr)
 #endif
@@ -349,14 +349,15 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     // sample index / decision vector of this lane's sample-eval: ONE scalar 64-bit division per wavefront (its first sample-eval),
     // then a wrap per lane -- a per-lane e / N, e % N is ~100 VALU instructions of the wave's 3400
     const long long ew0u = ((long long)__builtin_amdgcn_readfirstlane((int)(ew0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ew0);
-    const long long b0 = ew0u / N;
+    const long long b0v = ew0u / N;
+    const long long b0 = ((long long)__builtin_amdgcn_readfirstlane((int)(b0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b0v);
     const int i0 = (int)(ew0u - b0 * N);
     int i = i0 + el;
     int wrap = 0;
     while (i >= N) { i -= N; wrap++; }  // (N >= 8 in every configuration of the reference: at most once)
     const long long b = b0 + wrap;
     // the run structure of this wave's sample-evals (wave-uniform): they start at sample i0 of decision vector b0
-    const int cntw = (int)((E - ew0 < 8) ? ((E - ew0 > 0) ? E - ew0 : 0) : 8);
+    const int cntw = (int)((E - ew0u < 8) ? ((E - ew0u > 0) ? E - ew0u : 0) : 8);
 
     // ---- every global load of the dynamics phases is issued (and awaited) HERE, before the first store: the vector-memory
     // counter of gfx9 retires loads and stores in issue order, so a load behind a store waits for that store's round trip to HBM ----
@@ -393,7 +394,11 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
 
     if (e < E) {
         const double* z = Z + b * L.n;  // L.n == 7 for ArmourBezierCurves
-        const size_t rowbase = (size_t)b * L.m;
+        // row addresses = a wave-uniform 64-bit base (decision vector b0) + a 32-bit per-lane offset (a lane of the next decision
+        // vector adds m): no 64-bit per-lane row index stays live through the kernel
+        double* const Gb = G + (size_t)b0 * L.m;
+        double* const Jb = JAC + (size_t)b0 * L.m * NV;
+        const int ro = wrap * L.m;
         const bool own = g < NV;  // lane 7 owns no joint
         const int gl = own ? g : NV - 1;
 
@@ -402,15 +407,15 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         double sq, cq;
         sincos_joint(q, &sq, &cq);
         if (own && G != nullptr) {  // JointLimits.cpp:34, VelocityLimits.cpp:33
-            G[rowbase + L.off_q + (size_t)i * NV + g] = q;
-            G[rowbase + L.off_qd + (size_t)i * NV + g] = qd;
+            Gb[ro + L.off_q + i * NV + g] = q;
+            Gb[ro + L.off_qd + i * NV + g] = qd;
         }
         if (DERIV && !RECORD && own) {
             // pq_pz / pq_d_pz rows (JointLimits.cpp:40-44, VelocityLimits.cpp:39-43; w * identity per sample, ArmourBezierCurves.cpp:147-151)
             // straight from registers, like the torque rows of phase E: lane g writes column g of the 7 x 7 block, the 7 lanes of a
             // group one 56-byte row per store
-            double* qrow = JAC + (rowbase + L.off_q + (size_t)i * NV) * NV + g;
-            double* vrow = JAC + (rowbase + L.off_qd + (size_t)i * NV) * NV + g;
+            double* qrow = Jb + (ro + L.off_q + i * NV) * NV + g;
+            double* vrow = Jb + (ro + L.off_qd + i * NV) * NV + g;
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 qrow[j * NV] = (j == g) ? pw0 : 0.0;
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         // ---- phase D: joint torque, and the per-joint 6-vectors of the analytic derivative ----
         if (own && G != nullptr) {
             // InverseDynamics.cpp:115-121 (damping, friction); armature inside pinocchio::rnea (>= 3)
-            G[rowbase + L.off_tau + (size_t)i * NV + g] =
+            Gb[ro + L.off_tau + i * NV + g] =
                 dot(s, F) + ptau_own;
         }
         double w0 = 0.0;
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
                     }
                 }
             } else if (own) {
-                double* trow = JAC + (rowbase + L.off_tau + (size_t)i * NV) * NV + g;
+                double* trow = Jb + (ro + L.off_tau + i * NV) * NV + g;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     double d;
@@ -619,10 +624,10 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         for (int sp = g; sp < lim; sp += 2 * KG) {
             const bool two = sp + KG < lim;
             const int sp2 = two ? sp + KG : sp;
-            const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
-            const size_t row2 = rowbase + L.off_obs + (size_t)i * ns + sp2;
+            const int row = ro + L.off_obs + i * ns + sp;
+            const int row2 = ro + L.off_obs + i * ns + sp2;
             if (O == 0) {  // :80-82, g / pg_pz keep their zero initialisation
-                if (G != nullptr) { G[row] = 0.0; G[row2] = 0.0; }
+                if (G != nullptr) { Gb[row] = 0.0; Gb[row2] = 0.0; }
                 if (DERIV)
 #pragma unroll
                     for (int c = 0; c < NV; c++) { srow[sp * NV + c] = 0.0; srow[sp2 * NV + c] = 0.0; }
@@ -640,8 +645,8 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
             const BoxHit hit = box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
             const BoxHit hit2 = box_hit(reinterpret_cast<const double*>(boxes + bidx2), sj.point);
             if (G != nullptr) {  // KinovaCustomizedConstraints.cpp:145
-                G[row] = hit.dist - si.radius;
-                if (two) G[row2] = hit2.dist - sj.radius;
+                Gb[row] = hit.dist - si.radius;
+                if (two) Gb[row2] = hit2.dist - sj.radius;
             }
             if (DERIV) {
                 const V3 dw = hit.n * w0, dw2 = hit2.n * w0;
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
         if (split_tail) {
 #pragma unroll 1
             for (int sp = full; sp < ns; sp++) {
-                const size_t row = rowbase + L.off_obs + (size_t)i * ns + sp;
+                const int row = ro + L.off_obs + i * ns + sp;
                 const SphereInfo si = sphere_info(lds, se, sp);
                 double bkey = 1e300;
                 int bidx = 0x7fffffff;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
                 ARGMIN_STEP(0x141) ARGMIN_STEP(0x4E) ARGMIN_STEP(0xB1)
 #undef ARGMIN_STEP
                 const BoxHit hit = box_hit(reinterpret_cast<const double*>(boxes + bidx), si.point);
-                if (g == 0 && G != nullptr) G[row] = hit.dist - si.radius;
+                if (g == 0 && G != nullptr) Gb[row] = hit.dist - si.radius;
                 if (DERIV) {  // lane c = column c, with its own joint axis still in registers
                     const V3 dw = hit.n * w0;
                     const SV Wr = SV{cross(si.point, dw), dw};
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     const double* rows = wbase + KW_X;
     if (RECORD) {  // sphere gradients per joint -> the records
         for (int k = 0; k < cntw; k++)
-            for (int r = lane; r < rowlen; r += 64) JAC[(size_t)(ew0 + k) * KREC_STRIDE + KREC_G + r] = rows[k * rowlen + r];
+            for (int r = lane; r < rowlen; r += 64) JAC[(size_t)(ew0u + k) * KREC_STRIDE + KREC_G + r] = rows[k * rowlen + r];
         return;
     }
     // ---- copy-out of the obstacle rows: one contiguous run per decision vector touched by this wave, 16 bytes per lane ----
