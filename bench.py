@@ -583,13 +583,17 @@ def pmc_valu(W, kms):
         simd_cycles = 1024 * 2.4e9 * ms * 1e-3  # 256 CUs x 4 SIMDs at 2.4 GHz
         # measured issue interval of independent fp64 VALU instructions on this part (scripts/valu_rate_probe.hip,
         # profiles/r2f_valu_rate_probe.txt), in 2.4 GHz cycles per wave-instruction and SIMD: 8.3 / 5.9 / 5.3 / 5.0 at 1 / 2 / 3 / >= 4
-        # wavefronts per SIMD -- the kernels here run at 2 (record kernels) so 5.9 is what their SIMDs can issue at best
+        # wavefronts per SIMD
         out.append({"kernel": key, "valu_wave_instructions": ent["SQ_INSTS_VALU"], "valu_busy": ent["SQ_INSTS_VALU"] * 4 / simd_cycles,
-                    "valu_busy_at_measured_issue_rate_2_waves": ent["SQ_INSTS_VALU"] * 5.9 / simd_cycles,
+                    "valu_busy_at_measured_issue_rate": {"2_waves_per_simd": ent["SQ_INSTS_VALU"] * 5.9 / simd_cycles,
+                                                         "3_waves_per_simd": ent["SQ_INSTS_VALU"] * 5.3 / simd_cycles,
+                                                         "4_or_more": ent["SQ_INSTS_VALU"] * 5.0 / simd_cycles},
                     "executed_fp64_tflops_upper_bound": ent["SQ_INSTS_VALU"] * 64 * 2 / (ms * 1e-3) / 1e12})
     return {"per_kernel": out, "stale": _pmc_stale(),
             "note": "valu_busy prices a wave-instruction at the nominal 4 cycles at 2.4 GHz; the measured issue interval of fp64 VALU "
-                    "instructions is 5.0 such cycles at >= 4 wavefronts per SIMD and 5.9 at 2 (profiles/r2f_valu_rate_probe.txt)"} if out else None
+                    "instructions is 5.0 such cycles at >= 4 wavefronts per SIMD, 5.3 at 3 and 5.9 at 2 (profiles/r2f_valu_rate_probe.txt; "
+                    "the figures assume every instruction is fp64, so values above 1 mean part of the mix is cheaper); kinova_fused_kernel "
+                    "runs at 3 wavefronts per SIMD (11 per CU by LDS), the legged record kernels at 2"} if out else None
 
 
 def _cpu_cores():
