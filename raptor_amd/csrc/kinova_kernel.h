@@ -31,7 +31,7 @@
 #define KIN_BLOCK 64   // lanes per workgroup: one wavefront (measured 64 / 128 / 256 / 512 lanes: 0.52 / 0.52 / 0.525 / 0.62 ms; run-to-run noise 1 %)
 #endif
 #ifndef KIN_WGS
-#define KIN_WGS 3      // waves per SIMD asked of the register allocation (168 VGPRs; LDS lets 11 one-wavefront workgroups share a CU)
+#define KIN_WGS 3      // waves per SIMD asked of the register allocation (168 VGPRs; 13.3 KB of LDS per one-wavefront workgroup: twelve share a CU)
 #endif
 #define K_EPB (KIN_BLOCK / KG)   // sample-evals per workgroup
 #define K_WAVES (KIN_BLOCK / 64)
@@ -40,22 +40,23 @@
 //   winner's box, whose index differs between lanes, comes through the vector L1 -- a copy of the box table in this header was
 //   measured slower once two spheres per lane hide that latency, 0.580 against 0.572 ms.)
 #define KH_SPH 0                       // [sphere][4]: offset x y z, radius
-#define KH_SPI (4 * RAPTOR_MAX_SPHERES) // [sphere] two ints: joint id, pose slot
-#define KH_SIZE (5 * RAPTOR_MAX_SPHERES)
+// then [sphere] two ints (joint id, pose slot) from 4 * ns on; the header is 5 * ns doubles rounded up to an even count (16-byte aligned
+// wave areas), sized by the problem's own sphere count so that TWELVE wavefronts' areas fit the CU's 160 KB (three per SIMD)
+__host__ __device__ inline int kinova_header_doubles(int ns) { return (5 * ns + 1) & ~1; }
 //   then one area per wavefront (8 sample-evals, el = 0..7):
 //     el * KW_E  + KL_S   s_j                     7 x 6
-//     el * KW_E  + KL_RO  R, o of up to 4 sphere-carrying links   4 x 12
+//     el * KW_E  + KL_RO  first two columns of R and o of up to 4 sphere-carrying links   4 x 9  (the third column is their cross product)
 //     KW_X + el * KW_XE   IS_j, BtS_j             7 x 12        (phase D -> E)
 //     KW_X + el * 7 ns    sphere rows [sphere][7] (after phase E: the rows of the wave's 8 sample-evals are CONTIGUOUS, in the
 //                         order they have in pg_pz, so the copy-out is a straight 16-byte-per-lane stream with no index arithmetic)
-//   the per-sample-eval strides (90, 84, 7 ns = 119 doubles) put the four groups of a 32-lane half on disjoint banks.
 #define KL_S 0
 #define KL_RO 42
-#define KW_E 90
+#define KL_ROS 9   // doubles per pose slot
+#define KW_E 78
 #define KW_X (8 * KW_E)
 #define KW_XE 84
 __host__ __device__ inline int kinova_wave_doubles(int ns) { return KW_X + 8 * ((7 * ns > KW_XE) ? 7 * ns : KW_XE); }
-__host__ __device__ inline int kinova_lds_doubles(int ns) { return KH_SIZE + K_WAVES * kinova_wave_doubles(ns); }
+__host__ __device__ inline int kinova_lds_doubles(int ns) { return kinova_header_doubles(ns) + K_WAVES * kinova_wave_doubles(ns); }
 
 RD void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -273,17 +274,16 @@ struct SphereInfo {
     double radius;
     V3 point;
 };
-RD SphereInfo sphere_info(const double* hdr, const double* se, int sp) {
+RD SphereInfo sphere_info(const double* hdr, int ns, const double* se, int sp) {
     SphereInfo si;
-    const int2 js = reinterpret_cast<const int2*>(hdr + KH_SPI)[sp];
+    const int2 js = reinterpret_cast<const int2*>(hdr + 4 * ns)[sp];
     const double* t = hdr + KH_SPH + 4 * sp;
-    const double* ro = se + KL_RO + js.y * 12;
-    M3 R;
-#pragma unroll
-    for (int k = 0; k < 9; k++) R.m[k] = ro[k];
+    const double* ro = se + KL_RO + js.y * KL_ROS;
+    const V3 c0 = v3(ro[0], ro[1], ro[2]), c1 = v3(ro[3], ro[4], ro[5]);
+    const V3 c2 = cross(c0, c1);  // third column of the link's rotation
     si.jid = js.x;
     si.radius = t[3];
-    si.point = v3(ro[9], ro[10], ro[11]) + mul(R, v3(t[0], t[1], t[2]));
+    si.point = v3(ro[6], ro[7], ro[8]) + (c0 * t[0] + c1 * t[1] + c2 * t[2]);
     return si;
 }
 // Wave-level copy-out: `len` doubles to dst (8-byte aligned), 16 bytes per lane, from a contiguous LDS run
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     const int ns = S->num_spheres;
     const int O = S->num_obstacles;
     const int rowlen = NV * ns;  // doubles of sphere rows per sample-eval
-    double* wbase = lds + KH_SIZE + wv * kinova_wave_doubles(ns);
+    double* wbase = lds + kinova_header_doubles(ns) + wv * kinova_wave_doubles(ns);
     double* se = wbase + el * KW_E;          // s_j, link poses
     double* sx = wbase + KW_X + el * KW_XE;  // IS_j, BtS_j
     double* srow = wbase + KW_X + el * rowlen;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
     for (int t = tid; t < ns; t += KIN_BLOCK) {
         double* d = lds + KH_SPH + 4 * t;
         d[0] = S->offset[t][0]; d[1] = S->offset[t][1]; d[2] = S->offset[t][2]; d[3] = S->radius[t];
-        reinterpret_cast<int2*>(lds + KH_SPI)[t] = make_int2(S->joint_id[t], S->slot[t]);
+        reinterpret_cast<int2*>(lds + 4 * ns)[t] = make_int2(S->joint_id[t], S->slot[t]);
     }
     __syncthreads();
 
@@ -471,10 +471,10 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
             lds_put(se + KL_S + g * 6, s);
             const int slot = pslot;
             if (slot >= 0) {
-                double* ro = se + KL_RO + slot * 12;
-#pragma unroll
-                for (int k = 0; k < 9; k++) ro[k] = Rw.m[k];
-                ro[9] = ow.x; ro[10] = ow.y; ro[11] = ow.z;
+                double* ro = se + KL_RO + slot * KL_ROS;
+                ro[0] = Rw.m[0]; ro[1] = Rw.m[3]; ro[2] = Rw.m[6];  // column 0
+                ro[3] = Rw.m[1]; ro[4] = Rw.m[4]; ro[5] = Rw.m[7];  // column 1
+                ro[6] = ow.x; ro[7] = ow.y; ro[8] = ow.z;
             }
         }
 
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
                     for (int c = 0; c < NV; c++) { srow[sp * NV + c] = 0.0; srow[sp2 * NV + c] = 0.0; }
                 continue;
             }
-            const SphereInfo si = sphere_info(lds, se, sp), sj = sphere_info(lds, se, sp2);
+            const SphereInfo si = sphere_info(lds, ns, se, sp), sj = sphere_info(lds, ns, se, sp2);
             double bkey = 1e300, bkey2 = 1e300;
             int bidx = 0, bidx2 = 0;
 #pragma unroll 2
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(KIN_BLOCK, KIN_WGS) void kinova_fused_kernel(
 #pragma unroll 1
             for (int sp = full; sp < ns; sp++) {
                 const int row = ro + L.off_obs + i * ns + sp;
-                const SphereInfo si = sphere_info(lds, se, sp);
+                const SphereInfo si = sphere_info(lds, ns, se, sp);
                 double bkey = 1e300;
                 int bidx = 0x7fffffff;
                 for (int ob = g; ob < O; ob += KG) {
