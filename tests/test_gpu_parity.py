@@ -169,6 +169,21 @@ def test_single_sample_and_uniform_time(oracle, hip, kinova):
         check(Jh, Jo)
 
 
+def test_kinova_ragged_batches(oracle, hip, kinova):
+    """Batches whose sample-evals do not fill the last wavefront (8 per wavefront), wavefronts that straddle two or more decision
+    vectors (N < 8: several wraps per wavefront), N not a multiple of 8: the fused kernel derives (sample, decision vector) of a lane
+    from one division per wavefront plus a wrap, and addresses rows as a wave-uniform base plus a lane offset."""
+    for N, B, gripper in ((1, 9, False), (2, 5, False), (3, 7, True), (7, 11, False), (9, 4, False), (13, 3, True), (33, 2, False)):
+        po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=N, boxes=H.reach_boxes(O=7), gripper=gripper))
+        Z = np.random.default_rng(100 * N + B).uniform(-1, 1, (B, 7))
+        Go, Jo = po.eval_host(Z)
+        Gh, Jh = ph.eval_host(Z)
+        check(Gh, Go)
+        check(Jh, Jo)
+        Gg, _ = ph.eval_host(Z, A.EVAL_G)  # the value-only instantiation
+        check(Gg, Go)
+
+
 def test_error_behaviour_matches(oracle, hip, kinova):
     keep = []
     for api in (oracle, hip):
