@@ -470,6 +470,20 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
         rpy = v3(atan2(-Rf.m[5], Rf.m[8]), safe_asin(Rf.m[2]), atan2(-Rf.m[1], Rf.m[0]));  // Transform::getRPY (Transform.cpp:379-390)
     }
+    // The torso's and the swing foot's poses are what phase F1's column lanes need: they go to the (still unused) per-column scratch
+    // of F2 now, so that Rw / ow / Rsf / psf -- 24 doubles per lane -- do not stay live through phases E and F1 just to be shuffled.
+    if (DERIV && is_torso) {
+        double* o = sl + LL::TS;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = Rw.m[k];
+        o[9] = ow.x; o[10] = ow.y; o[11] = ow.z;
+    }
+    if (DERIV && is_sf) {
+        double* o = sl + LL::TS + 12;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = Rsf.m[k];
+        o[9] = psf.x; o[10] = psf.y; o[11] = psf.z;
+    }
     if (is_torso) {
         // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
         const V3 pd = v.l + cross(v.a, ow);
@@ -565,14 +579,16 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // no row structure, so one lane per column is the natural mapping.
     {
         const int tb = Q->torso_body, sb = (Q->ncust > 0) ? Q->sf_body : 0;
+        const bool has_sf = Q->ncust > 0;
+        const double* tp = sl + LL::TS;  // published in phase D (a wave_sync lies between)
         M3 Rt, Rs;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            Rt.m[k] = __shfl(Rw.m[k], tb, LG);
-            Rs.m[k] = __shfl(Rsf.m[k], sb, LG);
+            Rt.m[k] = tp[k];
+            Rs.m[k] = has_sf ? tp[12 + k] : 0.0;
         }
-        const V3 ot = v3(__shfl(ow.x, tb, LG), __shfl(ow.y, tb, LG), __shfl(ow.z, tb, LG));
-        const V3 ps = v3(__shfl(psf.x, sb, LG), __shfl(psf.y, sb, LG), __shfl(psf.z, sb, LG));
+        const V3 ot = v3(tp[9], tp[10], tp[11]);
+        const V3 ps = has_sf ? v3(tp[21], tp[22], tp[23]) : v3(0, 0, 0);
         const bool col = g < ni;
         const int t = col ? g : 0;
         unsigned long long cp = col ? Q->col_pack[t][0] : 0ull;
