@@ -264,9 +264,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
     for (int k = 0; k < 9; k++) Rw.m[k] = Q->R0[k];
     V3 ow = v3(Q->o0[0], Q->o0[1], Q->o0[2]);
-    SV v = sv_zero(), vprev = sv_zero();
+    SV vA = sv_zero(), vprevA = sv_zero();
     const SV a0 = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
-    SV a = a0;
+    SV aA = a0;
     SV s = sv_zero();
     const int depth = has_body ? Q->body_depth[gb] : 0;
 #pragma unroll 1
@@ -281,15 +281,15 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         const V3 oj = (x[17] != 0.0) ? ow : o;
         s = SV{axw, cross(oj, axw)};
         const SV sqd = s * x[15];
-        vprev = v;
-        a = a + s * x[16] + crm(v, sqd);
-        v = v + sqd;
+        vprevA = vA;
+        aA = aA + s * x[16] + crm(vA, sqd);
+        vA = vA + sqd;
         Rw = R;
         ow = o;
     }
-    const SV sd = crm(vprev, s);
+    const SV sdA = crm(vprevA, s);
 
-    LEG_PHASE_END(2, sv_sum(v) + sv_sum(a) + sv_sum(s) + sv_sum(sd) + Rw.m[0] + Rw.m[4] + Rw.m[8] + Rw.m[1] + Rw.m[5] + Rw.m[6] + ow.x + ow.y + ow.z)
+    LEG_PHASE_END(2, sv_sum(vA) + sv_sum(aA) + sv_sum(s) + sv_sum(sdA) + Rw.m[0] + Rw.m[4] + Rw.m[8] + Rw.m[1] + Rw.m[5] + Rw.m[6] + ow.x + ow.y + ow.z)
 
     // ---- phase B: this body's inertia, momentum, wrench, Coriolis block (world frame, about the origin) ----
     InertiaO I;
@@ -311,10 +311,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         I.xy = keep * Ic.xy - m * c.x * c.y;
         I.xz = keep * Ic.xz - m * c.x * c.z;
         I.yz = keep * Ic.yz - m * c.y * c.z;
-        h = applyO(I, v);
-        f = applyO(I, a) + crf(v, h);
+        h = applyO(I, vA);
+        f = applyO(I, aA) + crf(vA, h);
         if (DERIV) {
-            const V3 w = v.a, u = v.l;
+            const V3 w = vA.a, u = vA.l;
             const V3 c0 = cross(w, v3(I.xx, I.xy, I.xz));
             const V3 c1 = cross(w, v3(I.xy, I.yy, I.yz));
             const V3 c2 = cross(w, v3(I.xz, I.yz, I.zz));
@@ -326,6 +326,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             Qt[4] = c2.y + c1.z - (I.hv.y * u.z + u.y * I.hv.z);
             Qt[5] = 2.0 * c2.z - 2.0 * I.hv.z * u.z + uh;
         }
+    }
+
+    // v, a and sd are not touched again before phase E (the torso's lane aside): they wait in this lane's slot of the joint-vector
+    // area -- the local transforms there are dead since phase A -- instead of in 36 registers through the scans and the value phase,
+    // where the kernel's register peak (and its scratch spills, each reload a load behind stores) sits
+    double* const park = sl + LL::V + g * LEG_VEC;
+    wave_sync();  // every lane's walk has read the transforms
+    if (DERIV) {
+        lds_put(park, vA);
+        lds_put(park + 6, aA);
+        lds_put(park + 12, sdA);
     }
 
     // ---- phase C: subtree composites = suffix scan over the DFS order minus the suffix at the subtree's end ----
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #undef CUT
     }
 
-    LEG_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sd) + sv_sum(v) + sv_sum(a))
+    LEG_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sdA) + sv_sum(vA) + sv_sum(aA))
 
     // ---- phase D: values.  tau rows, q rows, contact rows; the same numbers go to the compact record ----
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
@@ -486,6 +497,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     if (is_torso) {
         // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
+        const SV v = DERIV ? lds_sv(park) : vA, a = DERIV ? lds_sv(park + 6) : aA;
         const V3 pd = v.l + cross(v.a, ow);
         const V3 rd = rpy_rates(Rw, v.a);
         const V3 al = a.a;  // gravity enters only the linear part of a0
@@ -542,9 +554,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
     }
     if (!DERIV) return;
-    LEG_PHASE_END(4, sv_sum(F) + sv_sum(H) + I.m + I.xx + Qt[0] + sv_sum(sd) + sv_sum(v) + sv_sum(a) + tt)
+    LEG_PHASE_END(4, sv_sum(F) + sv_sum(H) + I.m + I.xx + Qt[0] + sv_sum(sdA) + sv_sum(vA) + sv_sum(aA) + tt)
 
     // ---- phase E: per-joint 6-vectors of the analytic derivative ----
+    const SV v = lds_sv(park), a = lds_sv(park + 6), sd = lds_sv(park + 12);
+    wave_sync();  // (this lane's slot is rewritten below)
     const SV psi = crm(a, s) + crm(v, sd);
     const SV IS = applyO(I, s);
     SV BtS;
