@@ -36,12 +36,15 @@
 #define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
 template <int LG>
 struct LegLds {
     // phases 0/A: per-joint local transform (LEG_LOC doubles) ; phases E/F: per-joint 6-vectors (LEG_VEC doubles) -- same area
     static constexpr int V = 0;
     static constexpr int TS = LG * LEG_VEC;     // per-column scratch: T_q, T_v, T_a per joint
-    static constexpr int STRIDE = TS + LG * 3 + 2;  // LG = 32: 1250 doubles -> 2 sample-evals = 20 KB per wavefront, 8 waves per CU
+    static constexpr int TSS = 4;               // doubles per joint in that scratch (q, v, a, pad): a 16-byte and an 8-byte access
+    static constexpr int STRIDE = TS + LG * TSS;  // LG = 32: 1280 doubles -> 2 sample-evals = 20 KB per wavefront, 8 waves per CU exactly
 };
 
 // Utils::wrapToPi (Utils/include/Utils.h:59-68)
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec) {
     // lamrec (may be null; the component view raptor_constrained_id_lambda_host only): per sample-eval the tree torque of every
     // closed-loop joint and its derivative per unit (q, v, a) of every actuator,  tau[nrec] | T[it][x][nrec]
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     using LL = LegLds<LG>;
     constexpr int EPB = LEG_BLOCK / LG;
     const int tid = threadIdx.x;
@@ -328,16 +331,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
     }
 
-    // v, a and sd are not touched again before phase E (the torso's lane aside): they wait in this lane's slot of the joint-vector
-    // area -- the local transforms there are dead since phase A -- instead of in 36 registers through the scans and the value phase,
-    // where the kernel's register peak (and its scratch spills, each reload a load behind stores) sits
-    double* const park = sl + LL::V + g * LEG_VEC;
-    wave_sync();  // every lane's walk has read the transforms
-    if (DERIV) {
-        lds_put(park, vA);
-        lds_put(park + 6, aA);
-        lds_put(park + 12, sdA);
-    }
+    // (Rounds 2-3: v, a and sd used to wait in LDS across the scans of phase C.  With phase E ahead of the value phase the kernel
+    // needs 222 registers and spills nothing, and keeping them in registers runs the record kernels 1.262 -> 1.252 ms.)
+    wave_sync();  // every lane's walk has read the transforms before phase E rewrites the area
 
     // ---- phase C: subtree composites = suffix scan over the DFS order minus the suffix at the subtree's end ----
     SV F = f, H = h;
@@ -369,6 +365,41 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
 
     LEG_PHASE_END(3, sv_sum(F) + sv_sum(H) + I.m + I.hv.x + I.hv.y + I.hv.z + I.xx + I.xy + I.xz + I.yy + I.yz + I.zz + Qt[0] + Qt[1] + Qt[2] + Qt[3] + Qt[4] + Qt[5] + sv_sum(sdA) + sv_sum(vA) + sv_sum(aA))
+
+    // ---- phase E (runs BEFORE the value phase since round 3): per-joint 6-vectors of the analytic derivative.  After it the composite
+    // inertia, momentum and Coriolis block (22 doubles) are dead and IS / BtS (12) take their place, so the value phase below -- where
+    // the kernel's register peak sits, with every table and record load of phases D-F2 in flight before the first store -- runs with
+    // 20 registers more.  This phase has no global store, so those loads are still ahead of every store.
+    const bool is_torso = has_body && g == Q->torso_body;
+    SV BtS = sv_zero();
+    if (DERIV) {
+        const SV v = vA, a = aA, sd = sdA;
+        const SV psi = crm(a, s) + crm(v, sd);
+        const SV IS = applyO(I, s);
+        {
+            const SV IdS = applyO(I, sd);
+            const SV Ipsi = applyO(I, psi);
+            const SV QS = applyQ(Qt, H.l, s);
+            const SV QdS = applyQ(Qt, H.l, sd);
+            const SV HS = crf(s, H);
+            const SV HdS = crf(sd, H);
+            const SV cF = crf(s, F);
+            BtS = QS - HS;
+            const SV cv = IdS * 2.0 + QS + HS;
+            const SV cq_ = Ipsi + QdS + HdS + cF;
+            if (has_joint) {
+                double* vv = sl + LL::V + g * LEG_VEC;
+                lds_put(vv, s); lds_put(vv + 6, sd); lds_put(vv + 12, psi);
+                lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
+            }
+        }
+        if (is_torso) {  // the torso's twist and acceleration, which the value phase turns into the floating-base coordinates' rates
+            lds_put(sl + LL::TS + 24, v);
+            lds_put(sl + LL::TS + 30, a);
+        }
+        wave_sync();
+    }
+    LEG_PHASE_END(4, sv_sum(F) + sv_sum(BtS))
 
     // ---- phase D: values.  tau rows, q rows, contact rows; the same numbers go to the compact record ----
     const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
@@ -408,10 +439,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     if (DERIV && ndep > 0) {  // all twelve loads in flight together (a branch per joint would wait for each pair in turn)
         double k0[6], k1[6];
 #pragma unroll
-        for (int d = 0; d < 6; d++) {
+        for (int d = 0; d < 6; d++) {  // selected, not weighted by zero: a non-finite record 0 must not leak into a healthy actuator
             const double* ld = loops + ((size_t)e * Q->nrec + recb[d]) * 10;
-            k0[d] = ld[3 + myslot];
-            k1[d] = ld[4 + myslot];
+            const double l0 = ld[3 + myslot], l1 = ld[4 + myslot];
+            k0[d] = (d < ndep) ? l0 : 0.0;
+            k1[d] = (d < ndep) ? l1 : 0.0;
         }
 #pragma unroll
         for (int d = 0; d < 6; d++) {
@@ -419,6 +451,19 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             Kq[1] += k1[d] * tdep[d];
         }
     }
+    // What phase F2's projection needs of these tables, packed into two registers (six 5-bit bodies; count and the loop's two
+    // minimal columns): held as ~10 separate values across phases D-F1 they were spilled to scratch, and every scratch reload at the
+    // start of F2 is a load behind F1's thirty stores.  ind_loop_col is read here, before the first store, for the same reason.
+    const int jdep_ld = Q->joint_dep[jnt];
+    const int f1col = (LG == 32) ? (g & 15) : g;  // phase F1's column of this lane; its support list, fetched ahead of the stores too
+    const unsigned long long cp0_ld = (DERIV && f1col < ni) ? Q->col_pack[f1col][0] : 0ull;
+    const unsigned long long cp1_ld = (DERIV && f1col < ni) ? Q->col_pack[f1col][1] : 0ull;
+    unsigned dep_pk = 0u;
+#pragma unroll
+    for (int d = 0; d < 6; d++) dep_pk |= (unsigned)depb[d] << (5 * d);
+    const int lc0_ld = Q->ind_loop_col[tjc][0], lc1_ld = Q->ind_loop_col[tjc][1];
+    unsigned aux_pk = (unsigned)ndep | ((unsigned)((tj >= 0 ? lc0_ld : -1) & 15) << 3) | ((unsigned)((tj >= 0 ? lc1_ld : -1) & 15) << 7);
+    asm volatile("" : "+v"(dep_pk), "+v"(aux_pk));  // packed HERE (the compiler would sink the packing to F2 and spill the pieces)
     // the first round of customized rows: table entries before the stores as well
     const int cs0 = (Q->ncust > 0 && G != nullptr) ? cust_start[i] : 0, cs1 = (Q->ncust > 0 && G != nullptr) ? cust_start[i + 1] : 0;
     int crow0 = 0;
@@ -433,6 +478,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         rec[Q->c_v + jnt] = qd;
         rec[Q->c_a + jnt] = qdd;
         if (G != nullptr) G[rowbase + Q->off_q + (size_t)i * nv + jnt] = wrap_to_pi(q);  // ConstrainedJointLimits.cpp:57
+    }
+    if (DERIV && rc >= 0) {  // P_dep rows of the closed-loop joints (= Y1, DigitDynamicsConstraints.cpp:394)
+        double* pl = rec + Q->c_Pl + (jdep_ld - 6) * 2;
+        pl[0] = w0[0];
+        pl[1] = w1[0];
     }
     if (tj >= 0) {
         // actuated torque = G^T tau_tree: own joint plus the closed-loop joints this actuator drives
@@ -465,7 +515,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     // The torso's lane and the swing foot's lane both need roll / pitch / yaw of a frame (three atan2 / asin evaluations of a
     // few hundred instructions): they run that code together, once per wave, instead of one lane after the other.
-    const bool is_torso = has_body && g == Q->torso_body;
     const bool is_sf = Q->ncust > 0 && has_body && g == Q->sf_body;
     M3 Rsf;
 #pragma unroll
@@ -497,7 +546,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     }
     if (is_torso) {
         // floating-base coordinates from the torso pose (TalosDynamicsConstraints.cpp:208-222) and their rates
-        const SV v = DERIV ? lds_sv(park) : vA, a = DERIV ? lds_sv(park + 6) : aA;
+        const SV v = DERIV ? lds_sv(sl + LL::TS + 24) : vA, a = DERIV ? lds_sv(sl + LL::TS + 30) : aA;
         const V3 pd = v.l + cross(v.a, ow);
         const V3 rd = rpy_rates(Rw, v.a);
         const V3 al = a.a;  // gravity enters only the linear part of a0
@@ -554,39 +603,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
     }
     if (!DERIV) return;
-    LEG_PHASE_END(4, sv_sum(F) + sv_sum(H) + I.m + I.xx + Qt[0] + sv_sum(sdA) + sv_sum(vA) + sv_sum(aA) + tt)
+    LEG_PHASE_END(5, sv_sum(F) + sv_sum(BtS) + tt)
 
-    // ---- phase E: per-joint 6-vectors of the analytic derivative ----
-    const SV v = lds_sv(park), a = lds_sv(park + 6), sd = lds_sv(park + 12);
-    wave_sync();  // (this lane's slot is rewritten below)
-    const SV psi = crm(a, s) + crm(v, sd);
-    const SV IS = applyO(I, s);
-    SV BtS;
-    {
-        const SV IdS = applyO(I, sd);
-        const SV Ipsi = applyO(I, psi);
-        const SV QS = applyQ(Qt, H.l, s);
-        const SV QdS = applyQ(Qt, H.l, sd);
-        const SV HS = crf(s, H);
-        const SV HdS = crf(sd, H);
-        const SV cF = crf(s, F);
-        BtS = QS - HS;
-        const SV cv = IdS * 2.0 + QS + HS;
-        const SV cq_ = Ipsi + QdS + HdS + cF;
-        if (has_joint) {
-            double* vv = sl + LL::V + g * LEG_VEC;
-            lds_put(vv, s); lds_put(vv + 6, sd); lds_put(vv + 12, psi);
-            lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
-        }
-    }
-    const int lc0 = (tj >= 0) ? Q->ind_loop_col[tj][0] : -1, lc1 = (tj >= 0) ? Q->ind_loop_col[tj][1] : -1;
-    if (rc >= 0) {  // P_dep rows of the closed-loop joints (= Y1, DigitDynamicsConstraints.cpp:394)
-        double* pl = rec + Q->c_Pl + (Q->joint_dep[jnt] - 6) * 2;
-        pl[0] = w0[0];
-        pl[1] = w1[0];
-    }
-    wave_sync();
-    LEG_PHASE_END(6, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1])
 
     // ---- phase F1: column pass.  Lane t < ni = actuator column t: d(root wrench), torso twist, swing-foot twist per unit
     // (q, v, a) of actuator t, summed over the tree joints that move with it (<= 8).  These are whole-tree quantities with
@@ -594,7 +612,62 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     {
         const int tb = Q->torso_body, sb = (Q->ncust > 0) ? Q->sf_body : 0;
         const bool has_sf = Q->ncust > 0;
-        const double* tp = sl + LL::TS;  // published in phase D (a wave_sync lies between)
+        // LG = 32: a column's (up to) eight support joints are shared by lanes t and t + 16, four each, and the halves are added by
+        // one exchange afterwards; the loop ends when no lane of the wavefront has an entry left (Talos / G1: one pass instead of eight).
+        // Reads are unconditional (an absent entry reads joint 1 with zero weights): under `if (on)` they were a divergent branch with
+        // its own LDS round trip per pass.
+        constexpr bool SPLIT = LG == 32;
+        const int t_ = SPLIT ? (g & 15) : g;
+        const bool upper = SPLIT && g >= 16;
+        const bool col = t_ < ni && (!SPLIT || g < 16);   // the lanes that own a column's outputs
+        const int t = (t_ < ni) ? t_ : 0;
+        unsigned long long cp = (t_ < ni) ? (upper ? cp1_ld : cp0_ld) : 0ull;
+        SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), twt = sv_zero(), tws = sv_zero();
+        unsigned long long cpn = SPLIT ? 0ull : ((t_ < ni) ? cp1_ld : 0ull);  // unsplit: entries 4..7 follow
+        const int has_cust = Q->ncust > 0;
+#pragma unroll 1
+        for (int r = 0; r < (SPLIT ? 4 : 8); r++) {
+            if (!SPLIT && r == 4) cp = cpn;
+            const unsigned ent = (unsigned)cp & 0xffffu;
+            cp >>= 16;
+            const bool on = (ent >> 12 & 1u) != 0;
+            if (__builtin_amdgcn_ballot_w64(on) == 0ull && (SPLIT || r >= 4 || __builtin_amdgcn_ballot_w64(cpn != 0ull) == 0ull)) break;  // (uniform)
+            const int k = on ? (int)(ent & 31u) : 1;
+            const bool s1 = (ent >> 11 & 1u) != 0;
+            // (both slots are fetched: the slot is the REQUESTING lane's choice, a select on the source side would use the source's)
+            const double a0 = __shfl(w0[0], k, LG), a1 = __shfl(w0[1], k, LG), a2 = __shfl(w0[2], k, LG);
+            const double b0 = __shfl(w1[0], k, LG), b1 = __shfl(w1[1], k, LG), b2 = __shfl(w1[2], k, LG);
+            const double g0 = on ? (s1 ? b0 : a0) : 0.0, hv = on ? (s1 ? b1 : a1) : 0.0, hq = on ? (s1 ? b2 : a2) : 0.0;
+            const v2d_t* vk = reinterpret_cast<const v2d_t*>(sl + LL::V + k * LEG_VEC);
+            v2d_t u[12];
+#pragma unroll
+            for (int c = 0; c < 3; c++) u[c] = vk[c];
+#pragma unroll
+            for (int c = 3; c < 12; c++) u[c] = vk[6 + c];
+            const SV sk = SV{v3(u[0].x, u[0].y, u[1].x), v3(u[1].y, u[2].x, u[2].y)};
+            const SV ISk = SV{v3(u[3].x, u[3].y, u[4].x), v3(u[4].y, u[5].x, u[5].y)};
+            const SV cvk = SV{v3(u[6].x, u[6].y, u[7].x), v3(u[7].y, u[8].x, u[8].y)};
+            const SV cqk = SV{v3(u[9].x, u[9].y, u[10].x), v3(u[10].y, u[11].x, u[11].y)};
+            Fa = Fa + ISk * g0;
+            Fv = Fv + cvk * g0 + ISk * hv;
+            Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
+            const int kend = (int)(ent >> 5 & 63u);
+            const double gt = (tb >= k && tb < kend) ? g0 : 0.0;
+            const double gs = (has_cust && sb >= k && sb < kend) ? g0 : 0.0;
+            twt = twt + sk * gt;
+            tws = tws + sk * gs;
+        }
+        if (SPLIT) {
+#define XADD(x) x += __shfl_xor(x, 16, LG);
+#define XADDSV(w) XADD(w.a.x) XADD(w.a.y) XADD(w.a.z) XADD(w.l.x) XADD(w.l.y) XADD(w.l.z)
+            XADDSV(Fq) XADDSV(Fv) XADDSV(Fa) XADDSV(twt) XADDSV(tws)
+#undef XADDSV
+#undef XADD
+        }
+        LEG_PHASE_END(6, sv_sum(BtS) + Kq[0] + Kq[1] + sv_sum(Fq) + sv_sum(Fv) + sv_sum(Fa) + sv_sum(twt) + sv_sum(tws))
+        // the torso's and the swing foot's poses, published in phase D (a wave_sync lies between): read after the loop -- held across it
+        // two of these 24 doubles went to scratch, and their reloads sat behind this phase's own stores
+        const double* tp = sl + LL::TS;
         M3 Rt, Rs;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
@@ -603,34 +676,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
         const V3 ot = v3(tp[9], tp[10], tp[11]);
         const V3 ps = has_sf ? v3(tp[21], tp[22], tp[23]) : v3(0, 0, 0);
-        const bool col = g < ni;
-        const int t = col ? g : 0;
-        unsigned long long cp = col ? Q->col_pack[t][0] : 0ull;
-        const unsigned long long cp1 = col ? Q->col_pack[t][1] : 0ull;
-        SV Fq = sv_zero(), Fv = sv_zero(), Fa = sv_zero(), twt = sv_zero(), tws = sv_zero();
-#pragma unroll 1
-        for (int r = 0; r < 8; r++) {
-            const unsigned ent = (unsigned)cp & 0xffffu;
-            cp >>= 16;
-            if (r == 3) cp = cp1;
-            const bool on = (ent >> 12 & 1u) != 0;
-            const int k = on ? (int)(ent & 31u) : 1;
-            const bool s1 = (ent >> 11 & 1u) != 0;
-            const double a0 = __shfl(w0[0], k, LG), a1 = __shfl(w0[1], k, LG), a2 = __shfl(w0[2], k, LG);
-            const double b0 = __shfl(w1[0], k, LG), b1 = __shfl(w1[1], k, LG), b2 = __shfl(w1[2], k, LG);
-            if (on) {
-                const double g0 = s1 ? b0 : a0, hv = s1 ? b1 : a1, hq = s1 ? b2 : a2;
-                const double* vk = sl + LL::V + k * LEG_VEC;
-                const SV sk = lds_sv(vk), ISk = lds_sv(vk + 18), cvk = lds_sv(vk + 24), cqk = lds_sv(vk + 30);
-                Fa = Fa + ISk * g0;
-                Fv = Fv + cvk * g0 + ISk * hv;
-                Fq = Fq + cqk * g0 + cvk * (0.5 * hv) + ISk * hq;
-                const int kend = (int)(ent >> 5 & 63u);
-                if (tb >= k && tb < kend) twt = twt + sk * g0;
-                if (Q->ncust > 0 && sb >= k && sb < kend) tws = tws + sk * g0;
-            }
-        }
-        LEG_PHASE_END(7, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1] + sv_sum(Fq) + sv_sum(Fv) + sv_sum(Fa) + sv_sum(twt) + sv_sum(tws))
         if (col) {
 #pragma unroll
             for (int x = 0; x < 3; x++) {  // d(lambda.tail(6)) = root wrench about the contact point, RPY rows through A_des
@@ -660,7 +705,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         }
     }
 
-    LEG_PHASE_END(5, sv_sum(BtS) + sv_sum(IS) + Kq[0] + Kq[1])
+    LEG_PHASE_END(7, sv_sum(BtS) + Kq[0] + Kq[1])
 
     // ---- phase F2: row pass.  Lane = tree joint j (row), loop over actuator columns `it` and the joints k that move with
     // it.  One code path for both relations: with (A, U1, U2, U3) = (s_j; IS_k, cv_k, cq_k) when j is a strict ancestor of
@@ -675,22 +720,82 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // << 15 | column of set 1 << 19 (15: none); mode 0 / 1: into set 0 / 1 with weight slot `slot`, 2: into both, slot 0 / slot 1.
     const int flat = flat_pre;  // loaded in phase 0
     const int nflat = Q->flat_n;
+    const int cD = Q->c_D;  // (read once: behind the wave_sync fences of the loop the compiler reloads every Q-> field it touches)
+    // the shuffles below address lanes through a lane id formed HERE (two VALU): the one from the top of the kernel had been spilled,
+    // and its reload -- a scratch load behind F1's thirty stores -- was the first thing this phase waited for
+    int lane_f2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_f2));
+    const int grp_f2 = lane_f2 & ~(LG - 1);
+    auto shfl_f2 = [&](const double x, const int k) {
+        const int a = (grp_f2 | k) << 2;
+        const long long xi = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_ds_bpermute(a, (int)(xi & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(a, (int)(xi >> 32));
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    struct F2Ops {
+        SV U1, U2, U3;
+    };
+    auto f2_fetch = [&](const int idx) {
+        F2Ops P;
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane(flat, idx);
+        const int k = (int)(ent & 31u);
+        const bool anc = has_joint && k > g && k < gend;
+        // 16-byte reads (the slot, the wavefront's area and the anc offset are all multiples of 16 bytes): ds_read_b128 moves 256 B per
+        // LDS clock, the ds_read2_b64 the compiler picks for 8-byte-aligned doubles half of that -- and the LDS is as busy as the VALU here
+        const v2d_t* vk = reinterpret_cast<const v2d_t*>(sl + LL::V + k * LEG_VEC + (anc ? 18 : 0));
+        v2d_t u[9];
+#if defined(LEG_F2_PROBE) && LEG_F2_PROBE == 3  // measurement build: no vector reads
+        for (int c = 0; c < 9; c++) u[c] = v2d_t{s.a.x + c, IS.l.y + k};
+#else
+#pragma unroll
+        for (int c = 0; c < 9; c++) u[c] = vk[c];
+#endif
+        P.U1 = SV{v3(u[0].x, u[0].y, u[1].x), v3(u[1].y, u[2].x, u[2].y)};
+        P.U2 = SV{v3(u[3].x, u[3].y, u[4].x), v3(u[4].y, u[5].x, u[5].y)};
+        P.U3 = SV{v3(u[6].x, u[6].y, u[7].x), v3(u[7].y, u[8].x, u[8].y)};
+        return P;
+    };
+    // this joint's own s and IS come back from its LDS slot (written in phase E): held in registers from phase E on they were 24 of
+    // the value phase's and F1's live registers
+    SV sR = sv_zero(), ISR = sv_zero();
+    if (has_joint) {
+        const double* own = sl + LL::V + g * LEG_VEC;
+        sR = lds_sv(own);
+        ISR = lds_sv(own + 18);
+    }
     double Tq = 0.0, Tv = 0.0, Ta = 0.0, Xq = 0.0, Xv = 0.0, Xa = 0.0;
-#pragma unroll 1
-    for (int idx = 0; idx < nflat; idx++) {
+    auto f2_step = [&](const int idx, const F2Ops& P) {
         const unsigned ent = (unsigned)__builtin_amdgcn_readlane(flat, idx);
         const int k = (int)(ent & 31u), kend = (int)(ent >> 5 & 63u);
         const bool s1 = (ent >> 11 & 1u) != 0;  // uniform
         const unsigned mode = ent >> 13 & 3u;   // uniform
+        // chain-rule weights of joint k towards the step's column(s): the slot is chosen before the shuffle (uniform), the second
+        // set is fetched only where two columns are walked together
+        double wa[3], wb[3];
+        {
+            const bool sa = (mode == 2u) ? false : s1;
+#pragma unroll
+#if defined(LEG_F2_PROBE) && LEG_F2_PROBE == 2  // measurement build: no weight shuffles
+            for (int c = 0; c < 3; c++) wa[c] = sa ? w1[c] : w0[c];
+            if (false) {
+#else
+            for (int c = 0; c < 3; c++) wa[c] = shfl_f2(sa ? w1[c] : w0[c], k);
+            if (mode == 2u) {
+#endif
+#pragma unroll
+                for (int c = 0; c < 3; c++) wb[c] = shfl_f2(w1[c], k);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) wb[c] = wa[c];
+            }
+        }
         {
             const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
             const bool dsc = has_joint && g >= k && g < kend;    // k is this joint or one of its ancestors
-            const double* vk = sl + LL::V + k * LEG_VEC + (anc ? 18 : 0);
-            const SV A = anc ? s : IS;  // registers: per-lane LDS slots 288 B apart would bank-conflict on 128-bit reads
-            const SV U1 = lds_sv(vk), U2 = lds_sv(vk + 6), U3 = lds_sv(vk + 12);
-            double da = dot(A, U1);
-            const double t2 = dot(A, U2), t3 = dot(A, U3);
-            const double e2 = dot(BtS, U1), e3 = dot(BtS, U2);
+            const SV A = anc ? sR : ISR;  // registers: per-lane LDS slots 288 B apart would bank-conflict on 128-bit reads
+            double da = dot(A, P.U1);
+            const double t2 = dot(A, P.U2), t3 = dot(A, P.U3);
+            const double e2 = dot(BtS, P.U1), e3 = dot(BtS, P.U2);
             double dv = anc ? t2 : 2.0 * t2 + e2;
             double dq = anc ? t3 : t3 + e3;
             const double own = (g == k) ? 1.0 : 0.0;  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
@@ -699,31 +804,31 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const double rel = (anc || dsc) ? 1.0 : 0.0;
             da *= rel; dv *= rel; dq *= rel;
             if (mode != 1u) {  // set 0
-                const bool sb = (mode == 2u) ? false : s1;
-                const double g0 = __shfl(sb ? w1[0] : w0[0], k, LG), hv = __shfl(sb ? w1[1] : w0[1], k, LG),
-                             hq = __shfl(sb ? w1[2] : w0[2], k, LG);
+                const double g0 = wa[0], hv = wa[1], hq = wa[2];
                 Ta += da * g0;
                 Tv += dv * g0 + da * hv;
                 Tq += dq * g0 + dv * (0.5 * hv) + da * hq;
             }
             if (mode != 0u) {  // set 1
-                const bool sb = (mode == 2u) ? true : s1;
-                const double g0 = __shfl(sb ? w1[0] : w0[0], k, LG), hv = __shfl(sb ? w1[1] : w0[1], k, LG),
-                             hq = __shfl(sb ? w1[2] : w0[2], k, LG);
+                const double g0 = wb[0], hv = wb[1], hq = wb[2];
                 Xa += da * g0;
                 Xv += dv * g0 + da * hv;
                 Xq += dq * g0 + dv * (0.5 * hv) + da * hq;
             }
         }
-        if ((ent >> 12 & 1u) == 0) continue;  // more joints move with this column / pair of columns (uniform)
+        if ((ent >> 12 & 1u) == 0) return;  // more joints move with this column / pair of columns (uniform)
+#if defined(LEG_F2_PROBE) && LEG_F2_PROBE == 1  // measurement build: no projection / stores (sums kept alive by the last column's store)
+        if (idx + 1 < nflat) return;
+#endif
 #pragma unroll 1
         for (int set = 0; set < 2; set++) {
             const int it = (int)(set == 0 ? (ent >> 15 & 15u) : (ent >> 19 & 15u));
             if (it == 15) continue;  // uniform
             const double Sq = set == 0 ? Tq : Xq, Sv = set == 0 ? Tv : Xv, Sa = set == 0 ? Ta : Xa;
-            if (has_joint) {
-                double* ts = sl + LL::TS + g * 3;
-                ts[0] = Sq; ts[1] = Sv; ts[2] = Sa;
+            {   // every lane writes its slot (a lane without a joint holds zeros): the projection below reads slot 0 for absent entries
+                double* ts = sl + LL::TS + g * LL::TSS;
+                *reinterpret_cast<v2d_t*>(ts) = v2d_t{Sq, Sv};
+                ts[2] = Sa;
             }
             if (lamrec != nullptr && rc >= 0) {
                 const int nrec = Q->nrec;
@@ -733,22 +838,38 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             wave_sync();
             if (tj >= 0) {  // project the rows: G^T
                 double Rq = Sq, Rv = Sv, Ra = Sa;
+                unsigned dpk = dep_pk, apk = aux_pk;
+                asm volatile("" : "+v"(dpk), "+v"(apk));  // unpacked here, every time: hoisted out of the loop they are ten registers again
+                const int nd_ = (int)(apk & 7u);
+                // all reads in flight together, then selected: a read under `d < ndep` is a divergent branch with its own LDS round trip, six
+                // in a row per column (round 2's form: the projection and its stores were 0.08 of the row pass's 0.30 ms)
+                v2d_t tqv[6];
+                double ta_[6];
 #pragma unroll
                 for (int d = 0; d < 6; d++) {
-                    if (d < ndep) {
-                        const double* ts = sl + LL::TS + depb[d] * 3;
-                        Rq += gdep[d] * ts[0]; Rv += gdep[d] * ts[1]; Ra += gdep[d] * ts[2];
-                    }
+                    const double* ts = sl + LL::TS + (int)(dpk >> (5 * d) & 31u) * LL::TSS;
+                    tqv[d] = *reinterpret_cast<const v2d_t*>(ts);
+                    ta_[d] = ts[2];
                 }
-                if (it == lc0) Rq += Kq[0];
-                if (it == lc1) Rq += Kq[1];
-                double* D = rec + Q->c_D + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
+#pragma unroll
+                for (int d = 0; d < 6; d++) {
+                    const bool on = d < nd_;
+                    Rq += gdep[d] * (on ? tqv[d].x : 0.0); Rv += gdep[d] * (on ? tqv[d].y : 0.0); Ra += gdep[d] * (on ? ta_[d] : 0.0);
+                }
+                if (it == (int)(apk >> 3 & 15u)) Rq += Kq[0];
+                if (it == (int)(apk >> 7 & 15u)) Rq += Kq[1];
+                double* D = rec + cD + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
                 D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
             }
             wave_sync();
         }
         Tq = 0.0; Tv = 0.0; Ta = 0.0; Xq = 0.0; Xv = 0.0; Xa = 0.0;
-    }
+    };
+    // (Measured, round 3: requesting step idx + 1's vectors before the arithmetic of step idx -- the loop unrolled by two, two operand
+    // sets -- runs the record kernels 1.273 ms against 1.259: with two wavefronts per SIMD the other wavefront already covers the LDS
+    // latency, and the second copy of the loop body costs more than it hides.)
+#pragma unroll 1
+    for (int idx = 0; idx < nflat; idx++) f2_step(idx, f2_fetch(idx));
 }
 
 // Streams pg_pz out in Optimizer order.  One workgroup per sample-eval: the sample's record and the per-column Bernstein
@@ -757,7 +878,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 //   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
 //   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
 // 16-byte store of two adjacent columns
-typedef double v2d_t __attribute__((ext_vector_type(2)));
 RD void store2_stream(double* p, double a, double b) {
     v2d_t v = {a, b};
 #ifdef RAPTOR_NT_STORES
