@@ -179,12 +179,12 @@ def main() -> None:
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         # no launcher: start the ranks ourselves, as a child process, before this process has touched the GPU
-        import torch
+        from raptor_amd.launch import run_ranks, visible_gpu_count
 
-        visible = torch.cuda.device_count()  # counting devices does not initialise the GPU runtime
-        if visible < args.gpus:
+        visible = visible_gpu_count()  # KFD topology in sysfs: the HIP runtime stays unloaded in this (parent) process
+        if visible is not None and visible < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {visible} GPU(s) visible: refusing to report a smaller run")
-        from raptor_amd.launch import run_ranks
+        # (topology unreadable: every rank checks for its own GPU below and the launcher's exit code reports a missing one)
 
         sys.exit(run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(env_world) if env_world is not None else 1

@@ -16,12 +16,17 @@
  *     std::runtime_error), no exception ever crosses this boundary;
  *   - "d_" pointers are device (HBM) pointers, everything else is host memory;
  *   - objects are not thread-safe, exactly like the reference's.  A raptor_problem also owns
- *     device scratch (per-sample records, partial results) shared by all of its entry points: every call on one problem
- *     must be ordered after the previous one -- the same hip_stream, or an event / synchronisation between streams.
- *     Enqueuing raptor_eval_batch on one stream and raptor_eval_costs / raptor_eval_h_batch / a *_host call for the SAME
- *     problem on another without ordering them races on that scratch.  Different problems are independent.
- *   - *_host entry points are synchronous: they stage through HBM on a private stream of the problem and wait for that
- *     stream only (small transfers through a pinned buffer), never for the whole device.
+ *     device scratch (per-sample records, partial results) shared by all of its entry points: ASYNCHRONOUS calls on one
+ *     problem must be ordered after one another by the caller -- the same hip_stream, or an event / synchronisation
+ *     between streams (raptor_eval_batch on one stream and raptor_eval_costs / raptor_eval_h_batch for the SAME problem on
+ *     another, unordered, race on that scratch).  A *_host call is ordered by the library itself: every asynchronous entry
+ *     point records an event on the caller's stream once its work is enqueued, and every *_host entry point waits for the
+ *     problem's latest such event before it touches the scratch.  Different problems are independent.
+ *   - *_host entry points are synchronous.  raptor_eval_batch_host, raptor_eval_batch_status_host and raptor_eval_h_batch_host
+ *     (the per-iteration calls of a solver) stage through HBM on a private non-blocking stream of the problem and wait for
+ *     that stream only (small transfers through a pinned buffer), never for the whole device; the other *_host entry
+ *     points (component views, costs, objective, step link, dual arm, capsules) run on the null stream and end with
+ *     hipDeviceSynchronize.
  *
  * The same signatures are exported by the CPU oracle (oracle/liboracle.so) with the prefix
  * oracle_ instead of raptor_ (host pointers everywhere); the parity tests call both.
@@ -287,7 +292,7 @@ int raptor_eval_batch_host(raptor_problem* problem, const double* Z, int B, unsi
  *   d_violation[b] = max_r max(g_lb[r] - g[b][r], g[b][r] - g_ub[r], 0), NaN if a row is NaN; a problem is feasible in the
  *   sense of Optimizer::eval_g (Optimization/src/Optimizer.cpp:374-378) when d_violation[b] <= constr_viol_tol.
  *   d_G = the [B x m] output of raptor_eval_batch; asynchronous on hip_stream, stream-ordered after the call that wrote d_G.
- *   The first call on a problem uploads its bounds (one allocation).
+ *   Allocates and uploads nothing: the bounds are put on the device by the *_problem_create call.
  * A C++ host gathers d_violation (B doubles per rank, padded to ceil(total / world)) with one ncclAllGather: INTEGRATION.md.
  */
 int raptor_shard_range(long long total, int world, int rank, long long* first, long long* count);

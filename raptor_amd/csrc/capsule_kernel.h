@@ -107,19 +107,20 @@ __global__ __launch_bounds__(CAPS_BLOCK) void capsule_kernel(const double* __res
     }
     dist_out[idx] = best - r11 - r21;
     if (want_grad) {
-        // ---- per-pair scalars of the gradient (:162-271) ----
+        // ---- per-pair scalars of the gradient (:162-271): norm = |dist_vec|, slope_t / slope_u = half the derivative of the squared
+        // separation along t / u at the optimum ----
         const V3 dist_vec = d1 * tStar - d2 * uStar - d12;
-        double purple = sqrt(dot(dist_vec, dist_vec));
-        if (purple == 0) purple = 1e-6;
-        const double orange = a * tStar - b * uStar - c;
-        const double green = -b * tStar - e * uStar + f;
-        const double gradient_factor = 1 / (purple * purple * purple);
+        double norm = sqrt(dot(dist_vec, dist_vec));
+        if (norm == 0) norm = 1e-6;
+        const double slope_t = a * tStar - b * uStar - c;
+        const double slope_u = -b * tStar - e * uStar + f;
+        const double gradient_factor = 1 / (norm * norm * norm);
         double* o = prec + threadIdx.x * CAPS_REC;
         o[0] = d1.x; o[1] = d1.y; o[2] = d1.z; o[3] = d2.x; o[4] = d2.y; o[5] = d2.z; o[6] = d12.x; o[7] = d12.y; o[8] = d12.z;
-        o[9] = tStar; o[10] = uStar; o[11] = purple; o[12] = orange; o[13] = green; o[14] = gradient_factor;
-        o[15] = a / purple - gradient_factor * orange * orange;   // L11
-        o[16] = e / purple - gradient_factor * green * green;     // L22
-        o[17] = -b / purple - gradient_factor * orange * green;   // L12
+        o[9] = tStar; o[10] = uStar; o[11] = norm; o[12] = slope_t; o[13] = slope_u; o[14] = gradient_factor;
+        o[15] = a / norm - gradient_factor * slope_t * slope_t;   // L11
+        o[16] = e / norm - gradient_factor * slope_u * slope_u;     // L22
+        o[17] = -b / norm - gradient_factor * slope_t * slope_u;   // L12
         o[18] = r1; o[19] = r2; o[20] = (double)ind;
     }
     }
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(CAPS_BLOCK) void capsule_kernel(const double* __res
         const int i = t - pl * F;
         const double* o = prec + pl * CAPS_REC;
         const V3 d1 = v3(o[0], o[1], o[2]), d2 = v3(o[3], o[4], o[5]), d12 = v3(o[6], o[7], o[8]);
-        const double tStar = o[9], uStar = o[10], purple = o[11], orange = o[12], green = o[13], gradient_factor = o[14];
+        const double tStar = o[9], uStar = o[10], norm = o[11], slope_t = o[12], slope_u = o[13], gradient_factor = o[14];
         const double L11 = o[15], L22 = o[16], L12 = o[17], r1 = o[18], r2 = o[19];
         const int ind = (int)o[20];
         const V3 dist_vec = d1 * tStar - d2 * uStar - d12;
-        const V3 grey_int = d1 * tStar * tStar - d2 * tStar * uStar - d12 * tStar;
+        const V3 dnorm_vec = d1 * tStar * tStar - d2 * tStar * uStar - d12 * tStar;
         const V3 d1md2md12 = d1 - d2 - d12;
         const V3 hvec = d1 * -tStar + d2 * uStar + d12;
         const double* q11 = dP + (size_t)(pair0 + pl) * 12 * F;
@@ -156,30 +157,30 @@ __global__ __launch_bounds__(CAPS_BLOCK) void capsule_kernel(const double* __res
         const double pc = dot(d12, pd1) + dot(d1, pd12);
         const double pe = 2 * dot(d2, pd2);
         const double pf = dot(d2, pd12) + dot(d12, pd2);
-        const double lgrey = pa * tStar - pb * uStar - pc;
-        const double red = -pb * tStar + pe * uStar + pf;
-        const double grey = (dot(grey_int, pd1) - dot(grey_int, pd2) - dot(d1md2md12, pd12)) / (purple * purple);
-        const double dL1 = (tStar == 1) ? -(lgrey * purple - orange * grey) : 0.0;
-        const double dL2 = (tStar == 0) ? -(red * purple - green * grey) : 0.0;
-        const double dL3 = (uStar == 1) ? (lgrey * purple - orange * grey) : 0.0;
-        const double dL4 = (uStar == 0) ? (red * purple - green * grey) : 0.0;
+        const double dslope_t = pa * tStar - pb * uStar - pc;
+        const double dslope_u = -pb * tStar + pe * uStar + pf;
+        const double dnorm_col = (dot(dnorm_vec, pd1) - dot(dnorm_vec, pd2) - dot(d1md2md12, pd12)) / (norm * norm);
+        const double dL1 = (tStar == 1) ? -(dslope_t * norm - slope_t * dnorm_col) : 0.0;
+        const double dL2 = (tStar == 0) ? -(dslope_u * norm - slope_u * dnorm_col) : 0.0;
+        const double dL3 = (uStar == 1) ? (dslope_t * norm - slope_t * dnorm_col) : 0.0;
+        const double dL4 = (uStar == 0) ? (dslope_u * norm - slope_u * dnorm_col) : 0.0;
         const V3 comb = pd1 * -tStar + pd2 * uStar + pd12;
         const double Hin = dot(hvec, comb);
         double pt = 0.0, pu = 0.0;
         if (ind <= 3) {
-            const double H2 = red / purple + dL2 - dL4 - green * Hin * gradient_factor;
+            const double H2 = dslope_u / norm + dL2 - dL4 - slope_u * Hin * gradient_factor;
             pu = -H2 / L22;
         } else if (ind <= 7) {
-            const double H1 = lgrey / purple + dL1 - dL3 - orange * Hin * gradient_factor;
+            const double H1 = dslope_t / norm + dL1 - dL3 - slope_t * Hin * gradient_factor;
             pt = -H1 / L11;
         } else if (ind <= 9) {
-            const double H2 = red / purple + dL2 - dL4 - green * Hin * gradient_factor;
-            const double H1 = lgrey / purple + dL1 - dL3 - orange * Hin * gradient_factor;
+            const double H2 = dslope_u / norm + dL2 - dL4 - slope_u * Hin * gradient_factor;
+            const double H1 = dslope_t / norm + dL1 - dL3 - slope_t * Hin * gradient_factor;
             pt = (L12 * H2 - L22 * H1) / (L11 * L22 - L12 * L12);
             pu = (L12 * H2 - L22 * H1) / (L11 * L22 - L12 * L12);
         }
         const V3 colv = pd1 * tStar + d1 * pt - pd2 * uStar - d2 * pu - pd12;
-        grad_out[(size_t)pair0 * F + t] = dot(dist_vec, colv) / purple - r1 * pt - r2 * pu;
+        grad_out[(size_t)pair0 * F + t] = dot(dist_vec, colv) / norm - r1 * pt - r2 * pu;
     }
 }
 

@@ -96,7 +96,10 @@ struct DevLegged {
     int col_supp_body[RAPTOR_LEG_MAX_IND][8]; // ... their bodies ...
     int col_supp_slot[RAPTOR_LEG_MAX_IND][8]; // ... and which of their weight slots points at t
     // the same tables packed for the core kernel, which reads them once into registers instead of chasing them through
-    // dependent loads inside its loops: an entry is  body | end(body) << 5 | slot << 11 | flag << 12 | column << 13
+    // dependent loads inside its loops.  path8: one body per byte.  col_pack entry (16 bits): body | end(body) << 5 | slot << 11 |
+    // valid << 12.  flat entry (32 bits): body | end(body) << 5 | slot << 11 | last-of-column << 12 | mode << 13 | column of set 0 << 15 |
+    // column of set 1 << 19 (4 bits each, 15 = none; mode 0 / 1: into set 0 / 1 with weight slot `slot`, 2: into both sets).
+    // The 5-bit body field needs RAPTOR_LEG_MAX_BODIES <= 32, the 4-bit column fields RAPTOR_LEG_MAX_IND <= 15 (static_asserts in legged_setup).
     unsigned long long path8[RAPTOR_LEG_MAX_BODIES][3];     // path[g][0 .. depth-1], one byte each
     unsigned long long col_pack[RAPTOR_LEG_MAX_IND][2];     // col_supp_*[t][0..7], 16 bits each, flag = entry valid
     int flat_n, flat[64];                                   // all (column, support joint) pairs in column order, flag = last of its column

@@ -228,9 +228,14 @@ struct raptor_problem {
     // small-batch fork (launch_legged): a side stream for the reset-map kernels, events for fork / join (created on first use)
     hipStream_t side = nullptr;
     hipEvent_t ev_loops = nullptr, ev_core = nullptr, ev_side = nullptr;
+    // Ordering between the asynchronous entry points and the *_host ones (which run on hs.stream()): every asynchronous call records
+    // this event on the caller's stream when it has enqueued its work, every *_host call makes its private stream wait for it before
+    // it touches the problem's scratch (s_core, s_loops, s_hpart, s_Z / s_G / s_J).  Created with the problem (no allocation later).
+    hipEvent_t ev_async = nullptr;
+    bool async_pending = false;
     ~raptor_problem() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_loops, ev_core, ev_side})
+        for (hipEvent_t e : {ev_loops, ev_core, ev_side, ev_async})
             if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
     }
@@ -469,6 +474,27 @@ void upload_common(raptor_problem& p, const std::vector<double>& basis, const st
     p.d_traj.upload(&p.htraj, 1);
     p.d_basis.upload(basis.data(), basis.size());
     p.d_wsum.upload(wsum.data(), wsum.size());
+}
+
+double* scratch_device_address();  // (defined with the allocation-free eval_h entry point)
+// last step of every *_problem_create: what later calls must not have to allocate, upload or look up
+void finish_problem(raptor_problem& p) {
+    if (p.kind == 1) (void)scratch_device_address();  // raptor_eval_h_batch_noalloc: this device's workspace address, resolved here
+    if (!p.g_lb.empty()) {  // raptor_violation_batch reads the bounds on the device; they never change after create
+        p.d_glb.upload(p.g_lb.data(), p.g_lb.size());
+        p.d_gub.upload(p.g_ub.data(), p.g_ub.size());
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&p.ev_async, hipEventDisableTiming));
+}
+// an asynchronous entry point has enqueued work of `p` on the caller's stream `st`
+inline void mark_async(raptor_problem& p, hipStream_t st) {
+    if (p.ev_async == nullptr || st == p.hs.st) return;
+    HIP_CHECK(hipEventRecord(p.ev_async, st));
+    p.async_pending = true;
+}
+// a *_host entry point is about to use the problem's scratch on stream `st` (its private stream, or the null stream)
+inline void order_after_async(raptor_problem& p, hipStream_t st) {
+    if (p.async_pending) HIP_CHECK(hipStreamWaitEvent(st, p.ev_async, 0));
 }
 
 inline unsigned grid_for(long long total) { return (unsigned)((total + RAPTOR_BLOCK - 1) / RAPTOR_BLOCK); }
@@ -979,6 +1005,7 @@ int raptor_id_problem_create(const raptor_model* model, const raptor_traj_desc* 
     p->g_ub.assign(rows, 1e19);
     if (p->htraj.type == RAPTOR_TRAJ_PIECEWISE_BEZIER) p->hbasis = basis;  // raptor_cost_hessian_host reads the column weights
     upload_common(*p, basis, wsum);
+    finish_problem(*p);
     *out = p.release();
     API_CATCH
 }
@@ -1110,6 +1137,7 @@ int raptor_kinova_problem_create(const raptor_model* model, const raptor_kinova_
     if (p->kind == 3) p->hbasis = basis;
     p->d_spheres.upload(&S, 1);
     p->d_boxes.upload(boxes.data(), boxes.size());
+    finish_problem(*p);
     *out = p.release();
     API_CATCH
 }
@@ -1259,6 +1287,7 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
 
     // packed copies for the core kernel (device_types.h)
     static_assert(RAPTOR_LEG_MAX_DEPTH <= 24 && RAPTOR_LEG_MAX_BODIES <= 32, "packed path / entry layout");
+    static_assert(RAPTOR_LEG_MAX_IND <= 15, "flat entry: 4-bit column fields, 15 = none (and the core kernel's packed loop columns)");
     for (int g = 0; g < nb; g++)
         for (int d = 0; d < Q.body_depth[g]; d++) Q.path8[g][d >> 3] |= (unsigned long long)Q.path[g][d] << (8 * (d & 7));
     for (int t = 0; t < ni; t++)
@@ -1587,6 +1616,7 @@ int raptor_legged_problem_create(const raptor_model* model, const raptor_legged_
         S.period_sign = d->period.mirror_sign;
     }
     legged_setup(*p, model, S);
+    finish_problem(*p);
     *out = p.release();
     API_CATCH
 }
@@ -1747,6 +1777,7 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
     legged_setup(*p, model, S);
     p->d_digit.upload(D.get(), 1);
     p->has_digit = true;
+    finish_problem(*p);
     *out = p.release();
     API_CATCH
 }
@@ -1755,6 +1786,7 @@ int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, d
                                     double* tau, double* lambda, double* ptau_pz, double* plambda_pz) {
     API_TRY
     if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (p->kind != 2) throw std::runtime_error("dcPtr_ is not defined yet!");
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
@@ -1795,6 +1827,7 @@ int raptor_constrained_id_eval_host(raptor_problem* p, const double* Z, int B, d
 int raptor_constrained_id_lambda_host(raptor_problem* p, const double* Z, int B, double* lambda, double* plambda_pz) {
     API_TRY
     if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (p->kind != 2) throw std::runtime_error("dcPtr_ is not defined yet!");
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
@@ -1877,6 +1910,7 @@ int raptor_eval_batch(raptor_problem* p, const double* d_Z, int B, unsigned flag
     API_TRY
     if (!p) throw std::invalid_argument("null problem");
     eval_device(*p, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    mark_async(*p, (hipStream_t)stream);
     API_CATCH
 }
 
@@ -1895,10 +1929,7 @@ int raptor_violation_batch(raptor_problem* p, const double* d_G, int B, double* 
     if (!p || (B > 0 && (!d_G || !d_violation))) throw std::invalid_argument("null argument");
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
-    if (!p->d_glb.p) {
-        p->d_glb.upload(p->g_lb.data(), p->g_lb.size());
-        p->d_gub.upload(p->g_ub.data(), p->g_ub.size());
-    }
+    if (!p->d_glb.p) throw std::runtime_error("bounds are not on the device");  // (uploaded by *_problem_create; nothing is allocated here)
     hipLaunchKernelGGL(violation_kernel, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_G, p->d_glb.p, p->d_gub.p,
                        p->layout.m, d_violation);
     HIP_CHECK(hipGetLastError());
@@ -1922,6 +1953,7 @@ int raptor_eval_batch_status(raptor_problem* p, const double* d_Z, int B, unsign
     p->cur_status = d_status;
     p->cur_iterations = d_iterations;
     eval_device(*p, d_Z, B, flags, d_G, d_JAC, st);
+    mark_async(*p, st);
     API_CATCH
 }
 
@@ -1937,6 +1969,7 @@ int raptor_eval_batch_status_host(raptor_problem* p, const double* Z, int B, uns
     if (B == 0) return RAPTOR_OK;
     const size_t n = p->layout.n, m = p->layout.m;
     hipStream_t st = p->hs.stream();
+    order_after_async(*p, st);
     p->s_Z.ensure((size_t)B * n);
     if (wg) p->s_G.ensure((size_t)B * m);
     if (jac) p->s_J.ensure((size_t)B * m * n);
@@ -1966,6 +1999,7 @@ int raptor_eval_batch_host(raptor_problem* p, const double* Z, int B, unsigned f
     const size_t zb = (size_t)B * n * sizeof(double), gb = wg ? (size_t)B * m * sizeof(double) : 0,
                  jb = jac ? (size_t)B * m * n * sizeof(double) : 0;
     hipStream_t st = p->hs.stream();
+    order_after_async(*p, st);
     const bool pin = zb + gb + jb <= HostStage::kZeroCopyMax;
     char* h = pin ? p->hs.pinned(zb + gb + jb) : nullptr;
     if (pin) {
@@ -2000,6 +2034,7 @@ int raptor_eval_batch_host(raptor_problem* p, const double* Z, int B, unsigned f
 int raptor_trajectory_eval_host(raptor_problem* p, const double* Z, int B, double* q, double* q_d, double* q_dd) {
     API_TRY
     if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
     const size_t tot = (size_t)B * p->htraj.N * p->htraj.Nact;
@@ -2020,6 +2055,7 @@ int raptor_trajectory_eval_host(raptor_problem* p, const double* Z, int B, doubl
 int raptor_inverse_dynamics_eval_host(raptor_problem* p, const double* Z, int B, double* tau, double* ptau_pz) {
     API_TRY
     if (!p || (B > 0 && !Z)) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (B < 0) throw std::invalid_argument("B < 0");
     if (B == 0) return RAPTOR_OK;
     const int nv = p->hmodel.nv, N = p->htraj.N, n = p->layout.n;
@@ -2063,6 +2099,7 @@ int raptor_eval_costs(raptor_problem* p, const double* d_Z, int B, int num_costs
         hipLaunchKernelGGL(traj_cost_kernel, dim3((unsigned)(B * num_costs)), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_traj.p,
                            p->d_basis.p, p->d_wsum.p, d_Z, p->layout.n, num_costs, p->d_kinds.p, d_F, d_GRAD);
         HIP_CHECK(hipGetLastError());
+        mark_async(*p, st);
         return RAPTOR_OK;
     }
     launch_legged_core(*p, d_Z, B, nullptr, d_GRAD != nullptr, st);
@@ -2072,6 +2109,7 @@ int raptor_eval_costs(raptor_problem* p, const double* d_Z, int B, int num_costs
     hipLaunchKernelGGL(legged_cost_kernel, dim3((unsigned)(B * num_costs)), dim3(RAPTOR_BLOCK), 0, st, p->d_traj.p, p->d_leg.p,
                        p->d_basis.p, p->layout.n, p->s_core.p, num_costs, p->d_kinds.p, d_F, d_GRAD);
     HIP_CHECK(hipGetLastError());
+    mark_async(*p, (hipStream_t)stream);
     API_CATCH
 }
 
@@ -2103,6 +2141,7 @@ int raptor_cost_hessian_host(raptor_problem* p, int kind, double* HESS) {
 int raptor_eval_costs_host(raptor_problem* p, const double* Z, int B, int num_costs, const int* kinds, double* F, double* GRAD) {
     API_TRY
     if (!p || !kinds || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (B < 0 || num_costs < 0) throw std::invalid_argument("negative size");
     if (B == 0 || num_costs == 0) return RAPTOR_OK;
     const size_t n = p->layout.n;
@@ -2136,12 +2175,14 @@ int raptor_kinova_eval_objective(raptor_problem* p, const double* d_Z, int B, do
     hipLaunchKernelGGL(kinova_objective_kernel, dim3(grid_for(B)), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, p->d_traj.p,
                        p->d_basis.p, p->d_wsum.p, d_Z, p->d_qdes.p, p->tplan_n, B, d_F, d_GRAD);
     HIP_CHECK(hipGetLastError());
+    mark_async(*p, (hipStream_t)stream);
     API_CATCH
 }
 
 int raptor_kinova_eval_objective_host(raptor_problem* p, const double* Z, int B, double* F, double* GRAD) {
     API_TRY
     if (!p || (B > 0 && (!Z || !F))) throw std::invalid_argument("null argument");
+    order_after_async(*p, nullptr);  // null stream: after whatever the asynchronous entry points enqueued for this problem
     if (B < 0) throw std::invalid_argument("B < 0");
     if (p->kind != 1 || p->tplan_n < 0) throw std::invalid_argument("objective: raptor_kinova_set_objective has not been called");
     if (B == 0) return RAPTOR_OK;
@@ -2190,6 +2231,7 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
                            d_H);
     }
     HIP_CHECK(hipGetLastError());
+    mark_async(*p, (hipStream_t)stream);
     API_CATCH
 }
 
@@ -2217,6 +2259,8 @@ int raptor_eval_h_batch_noalloc(raptor_problem* p, const double* d_Z, int B, con
     hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, part, p->d_wsum.p,
                        d_obj_factor, tplan, B, d_H);
     HIP_CHECK(hipGetLastError());
+    // (no ordering event here: this entry point touches none of the problem's scratch, and a caller under stream capture must not
+    // have an event of ours captured into its graph)
     API_CATCH
 }
 
@@ -2229,6 +2273,7 @@ int raptor_eval_h_batch_host(raptor_problem* p, const double* Z, int B, const do
     const size_t zb = (size_t)B * n * sizeof(double), lb = (size_t)B * m * sizeof(double), ob = obj_factor ? (size_t)B * sizeof(double) : 0,
                  hb = (size_t)B * nh * sizeof(double);
     hipStream_t st = p->hs.stream();
+    order_after_async(*p, st);
     const bool pin = zb + lb + ob + hb <= HostStage::kPinMax;
     char* h = pin ? p->hs.pinned(zb + lb + ob + hb) : nullptr;
     if (pin) {
@@ -2373,6 +2418,7 @@ int raptor_step_link_eval_batch(raptor_problem* curr, raptor_problem* next, cons
     API_TRY
     if (!curr || !next) throw std::invalid_argument("null argument");
     step_link_device(*curr, *next, d_Zcurr, d_Znext, B, flags, d_G, d_JAC, d_JAC2, (hipStream_t)stream);
+    mark_async(*curr, (hipStream_t)stream);
     API_CATCH
 }
 
@@ -2380,6 +2426,8 @@ int raptor_step_link_eval_batch_host(raptor_problem* curr, raptor_problem* next,
                                      unsigned flags, double* G, double* JAC, double* JAC2) {
     API_TRY
     if (!curr || !next) throw std::invalid_argument("null argument");
+    order_after_async(*curr, nullptr);
+    if (next) order_after_async(*next, nullptr);
     if (B < 0) throw std::invalid_argument("negative batch size");
     if (B > 0 && (!Zcurr || !Znext)) throw std::invalid_argument("Z is null");
     const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;
@@ -2409,6 +2457,7 @@ int raptor_dual_kinova_arm_arm_batch(raptor_problem* p1, raptor_problem* p2, con
     API_TRY
     if (!p1 || !p2) throw std::invalid_argument("null argument");
     dual_arm_arm_device(*p1, *p2, d_Z, B, flags, d_G, d_JAC, (hipStream_t)stream);
+    mark_async(*p1, (hipStream_t)stream);
     API_CATCH
 }
 
@@ -2416,6 +2465,8 @@ int raptor_dual_kinova_arm_arm_batch_host(raptor_problem* p1, raptor_problem* p2
                                           double* G, double* JAC) {
     API_TRY
     if (!p1 || !p2) throw std::invalid_argument("null argument");
+    order_after_async(*p1, nullptr);
+    if (p2) order_after_async(*p2, nullptr);
     if (B < 0) throw std::invalid_argument("negative batch size");
     if (B > 0 && !Z) throw std::invalid_argument("Z is null");
     const bool jac = (flags & RAPTOR_EVAL_JAC) != 0;

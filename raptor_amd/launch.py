@@ -1,9 +1,10 @@
 """One process per GPU: start the ranks of a single-node job.
 
 `run_ranks` starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N <script> <argv>` as a CHILD process and
-returns its exit code.  The caller must not have touched the GPU (no HIP call, no `torch.cuda.is_available()`); counting devices
-with `torch.cuda.device_count()` is fine.  The ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
-(`dist_env`).  The reference has no counterpart: it is a single-process library.
+returns its exit code.  The caller must not have touched the GPU (no HIP call, no `torch.cuda.is_available()`).  To count the
+GPUs before launching use `visible_gpu_count()` below, which reads the KFD topology from sysfs and never loads the HIP runtime
+(`torch.cuda.device_count()` falls back to `hipGetDeviceCount` when its amdsmi query fails, which does initialise HIP).  The ranks
+read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (`dist_env`).  The reference has no counterpart: it is a single-process library.
 """
 from __future__ import annotations
 
@@ -12,6 +13,33 @@ import socket
 import subprocess
 import sys
 from typing import Dict, Optional, Sequence, Tuple
+
+
+def visible_gpu_count(topology: str = "/sys/class/kfd/kfd/topology/nodes") -> Optional[int]:
+    """GPUs this process would see, without touching the HIP runtime: KFD topology nodes with SIMDs, narrowed by the
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES lists.  None when the topology cannot be read (then the
+    per-rank check in the ranks themselves is what reports a missing GPU)."""
+    if not os.path.exists(os.path.dirname(topology)):
+        return 0  # no KFD device at all: no AMD GPU driver in this environment
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    gpus = 0
+    for n in nodes:
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(topology, n, "properties")).read().splitlines() if " " in l)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            gpus += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is None:
+            continue
+        listed = [x for x in val.split(",") if x.strip() != ""]
+        gpus = min(gpus, len(listed))
+    return gpus
 
 
 def free_port() -> int:

@@ -23,6 +23,33 @@ def check(a, b, tol=TOL):
     assert err <= tol, err
 
 
+def check_blocks(Gh, Jh, Go, Jo, po, tol=TOL):
+    """The 1e-9 of north_star as a RELATIVE bound per constraint block and decision vector:  max|hip - oracle| <= 1e-9 * max|oracle|
+    over the block's rows of g (and of pg_pz) for each z.  `check` above adds 1 to the denominator, so it cannot see a relative
+    error on a block whose entries are all small; this one can (a block that is all zeros in the oracle: |hip| <= 1e-13)."""
+    offs = sorted(set(int(o) for o in po.block_offsets if o >= 0)) + [po.m]
+    worst = 0.0
+    for o0, o1 in zip(offs[:-1], offs[1:]):
+        if o1 <= o0:
+            continue
+        for A_, B_ in ((Gh[:, o0:o1], Go[:, o0:o1]),) + (((Jh[:, o0:o1], Jo[:, o0:o1]),) if Jh is not None else ()):
+            A2 = np.asarray(A_).reshape(A_.shape[0], -1)
+            B2 = np.asarray(B_).reshape(B_.shape[0], -1)
+            if A2.shape[1] == 0:
+                continue
+            scale = np.abs(B2).max(axis=1)
+            err = np.abs(A2 - B2).max(axis=1)
+            zero = scale == 0.0
+            # a block that is identically zero in the oracle (e.g. the velocity rows of a single sample at t = T, where the Armour
+            # curve's end velocity cancels exactly) may hold the other side's cancellation residue: absolute bound there
+            assert np.all(err[zero] <= 1e-13), (o0, o1, float(err[zero].max(initial=0.0)))
+            rel = err[~zero] / scale[~zero]
+            if rel.size:
+                worst = max(worst, float(rel.max()))
+            assert np.all(err[~zero] <= tol * scale[~zero]), (o0, o1, float(rel.max(initial=0.0)))
+    return worst
+
+
 def both(oracle, hip, build):
     keep = []
     return build(oracle, keep), build(hip, keep), keep
@@ -101,6 +128,7 @@ def test_kinova_eval_g_and_jac(oracle, hip, kinova, env, gripper):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     # structural zeros of the joint/velocity-limit rows (diagonal pq_pz) are exact zeros
     off = po.block_offsets
     assert np.array_equal(Jh[:, : off[2]] == 0.0, Jo[:, : off[2]] == 0.0)
@@ -126,6 +154,7 @@ def test_kinova_obstacle_counts(oracle, hip, kinova, O, gripper):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     lam = rng.uniform(-1, 1, (7, po.m))
     for p_ in (po, ph):
         p_.set_objective(np.zeros(7), 4)
@@ -144,6 +173,7 @@ def test_kinova_points_inside_boxes(oracle, hip, kinova):
     assert (Go[:, po.block_offsets[3]:] < -0.05).mean() > 0.3  # the branch really is exercised
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
 
 
 def test_kinova_no_obstacles_and_empty_batch(oracle, hip, kinova):
@@ -154,6 +184,7 @@ def test_kinova_no_obstacles_and_empty_batch(oracle, hip, kinova):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     assert np.all(Gh[:, po.block_offsets[3]:] == 0) and np.all(Jh[:, po.block_offsets[3]:] == 0)
     Gh, Jh = ph.eval_host(np.zeros((0, 7)))
     assert Gh.shape == (0, ph.m) and Jh.shape == (0, ph.m, 7)
@@ -167,6 +198,7 @@ def test_single_sample_and_uniform_time(oracle, hip, kinova):
         Gh, Jh = ph.eval_host(Z)
         check(Gh, Go)
         check(Jh, Jo)
+        check_blocks(Gh, Jh, Go, Jo, po)
 
 
 def test_kinova_ragged_batches(oracle, hip, kinova):
@@ -180,6 +212,7 @@ def test_kinova_ragged_batches(oracle, hip, kinova):
         Gh, Jh = ph.eval_host(Z)
         check(Gh, Go)
         check(Jh, Jo)
+        check_blocks(Gh, Jh, Go, Jo, po)
         Gg, _ = ph.eval_host(Z, A.EVAL_G)  # the value-only instantiation
         check(Gg, Go)
 
@@ -200,6 +233,7 @@ def test_capsule_known_answers_and_random(oracle, hip):
     P, R, want = capsule_arrays()
     dist, _ = hip.capsule_distance_host(P, None, R)
     assert np.all(np.abs(dist - want) < 1e-4)
+    excluded_by_F = {}
     for F in (2, 7, 14, 42):
         P, dP, R = random_capsules(10 + F, 3000, F)
         do, go = oracle.capsule_distance_host(P, dP, R)
@@ -221,11 +255,20 @@ def test_capsule_known_answers_and_random(oracle, hip):
         assert np.isfinite(gh[ok]).all()
         err = np.abs(gh[ok] - go[ok]) / (1 + np.abs(go[ok]))
         excluded = 1.0 - ok.mean()
-        print(f"capsule gradient F={F}: max err {err.max():.2e} on {ok.sum()} well-conditioned pairs, excluded {100 * excluded:.2f} %")
-        assert err.max() <= TOL, err.max()
-        assert excluded <= 0.005, excluded
+        report = f"capsule gradient F={F}: max err {err.max():.2e} on {ok.sum()} well-conditioned pairs, excluded {100 * excluded:.3f} % ({(~ok).sum()} of {ok.size})"
+        print(report)
+        excluded_by_F[F] = excluded
+        assert err.max() <= TOL, report
+        assert excluded <= 0.005, report
         bad = ~ok & fin
         check(dh[bad], do[bad])
+    # the excluded fraction of every F, kept with the test's outcome (stored beside the other GPU-run records when the directory exists)
+    assert all(v <= 0.005 for v in excluded_by_F.values()), excluded_by_F
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({str(k): v for k, v in excluded_by_F.items()}, open(os.path.join(out, "capsule_excluded_fraction.json"), "w"))
 
 
 def test_dual_kinova_arm_arm_rows(oracle, hip, kinova):
@@ -342,6 +385,7 @@ def test_legged_eval_g_and_jac(oracle, hip, which):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     # structural zeros agree exactly: trailing v_reset / lambda_reset columns everywhere, and the independent-joint
     # rows of the joint-limit block (one Bernstein block per row)
     assert np.all(Jh[:, :, 84:] == 0.0) and np.all(Jo[:, :, 84:] == 0.0)
@@ -371,6 +415,7 @@ def test_legged_rotated_stance_foot_and_degree(oracle, hip):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
 
 
 def test_legged_odd_number_of_columns(oracle, hip):
@@ -389,17 +434,20 @@ def test_legged_odd_number_of_columns(oracle, hip):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
 
 
-def test_legged_full_size_properties(hip):
-    """BASELINE config 5 size on one GPU's shard (G1, 1024 problems x N = 14) through the device entry point."""
+@pytest.mark.parametrize("which", ["g1", "talos"])
+def test_legged_full_size_properties(hip, which):
+    """BASELINE config 5 size on one GPU's shard (G1, 1024 problems x N = 14) and config 3 (Talos, same size) through the device
+    entry point: every entry written, batch-order independence bit for bit, directional derivative against central differences."""
     import torch
 
     keep = []
-    p, m, cfg = H.legged_problem(hip, "g1", keep, N=14, customized=True, periodic=True)  # all 729 rows of the reference's problem
+    p, m, cfg = H.legged_problem(hip, which, keep, N=14, customized=True, periodic=True)  # all 729 rows of the reference's problem
     assert p.m == 729
     B = 1024
-    g = torch.Generator(device="cpu").manual_seed(20250527)
+    g = torch.Generator(device="cpu").manual_seed(20250527 if which == "g1" else 20250525)
     Z = (0.1 * (torch.rand(B, p.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
     G = torch.empty(B, p.m, dtype=torch.float64, device="cuda")
     J = torch.full((B, p.m, p.n), float("nan"), dtype=torch.float64, device="cuda")
@@ -516,6 +564,7 @@ def test_legged_sample_counts(oracle, hip, which, N):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
 
 
 def test_digit_eval_g_and_jac(oracle, hip):
@@ -534,6 +583,7 @@ def test_digit_eval_g_and_jac(oracle, hip):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     assert np.all(Jh[:, :, 72:] == 0.0) and np.all(Jo[:, :, 72:] == 0.0)
     Gh2, none = ph.eval_host(Z, A.EVAL_G)
     check(Gh2, Gh, 1e-12)
@@ -626,6 +676,7 @@ def test_customized_block(oracle, hip, robot, stance):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     Gh2, _ = ph.eval_host(Z, A.EVAL_G)
     check(Gh2, Gh, 1e-12)
 
@@ -659,6 +710,7 @@ def test_reset_map_block(oracle, hip, robot, stance, customized):
     check(Jh[:, -rows:], Jo[:, -rows:])
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     Gh2, _ = ph.eval_host(Z, A.EVAL_G)
     check(Gh2, Gh, 1e-12)
     if robot == "digit" and customized:
@@ -694,6 +746,7 @@ def test_constrained_initial_state(oracle, hip, robot, vel):
     Gh, Jh = ph.eval_host(Z)
     check(Gh, Go)
     check(Jh, Jo)
+    check_blocks(Gh, Jh, Go, Jo, po)
     kinds = [A.COST_MINIMIZE_POWER, A.COST_MINIMIZE_TORQUE, A.COST_MINIMIZE_INITIAL_VELOCITY, A.COST_MINIMIZE_INITIAL_ACCELERATION]
     Fo, Do = po.costs_host(Z, kinds)
     Fh, Dh = ph.costs_host(Z, kinds)

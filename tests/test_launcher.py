@@ -121,3 +121,22 @@ def test_shard_range_matches_c_abi():
 
     with pytest.raises(_capi.RaptorInvalidArgument):
         api.shard_range(5, 2, 2)
+
+
+def test_visible_gpu_count_reads_topology_without_hip(tmp_path, monkeypatch):
+    """The parent of a self-launched run counts GPUs from the KFD topology (sysfs), never through the HIP runtime."""
+    from raptor_amd.launch import visible_gpu_count
+
+    nodes = tmp_path / "topology" / "nodes"
+    for k, simd in enumerate((0, 1024, 1024, 0, 1024)):  # CPU nodes have no SIMDs
+        d = nodes / str(k)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert visible_gpu_count(str(nodes)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert visible_gpu_count(str(nodes)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert visible_gpu_count(str(nodes)) == 1
+    assert visible_gpu_count(str(tmp_path / "absent" / "nodes")) == 0

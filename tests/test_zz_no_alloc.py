@@ -59,3 +59,43 @@ def test_noalloc_limits(hip, kinova):
     pid = H.id_problem(hip, kinova, keep)
     with pytest.raises(A.RaptorError):
         pid.eval_h_device_noalloc(z.data_ptr(), 1, 0, lam.data_ptr(), out.data_ptr())
+
+
+def test_noalloc_allocates_no_device_memory(hip, kinova):
+    """The device's free memory (hipMemGetInfo) is the same before and after the call -- first call on a fresh problem included: the
+    workspace address was resolved by raptor_kinova_problem_create, the kernels' code object by an earlier launch of the library."""
+    keep = []
+    warm = H.kinova_problem(hip, kinova, keep, N=8)
+    rng = np.random.default_rng(7)
+    B = 16
+    _run(warm, warm.eval_h_device, rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, warm.m)), None)  # loads the code object
+    p = H.kinova_problem(hip, kinova, keep, N=8)  # a fresh problem: nothing of it has run yet
+    dZ = torch.from_numpy(rng.uniform(-1, 1, (B, 7))).cuda()
+    dl = torch.from_numpy(rng.uniform(-1, 1, (B, p.m))).cuda()
+    dH = torch.empty(B, 28, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        p.eval_h_device_noalloc(dZ.data_ptr(), B, 0, dl.data_ptr(), dH.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.isfinite(dH).all()
+
+
+def test_violation_batch_allocates_no_device_memory(hip, kinova):
+    """raptor_violation_batch is documented asynchronous: its bounds are on the device since the problem was created."""
+    keep = []
+    warm = H.kinova_problem(hip, kinova, keep, N=8, boxes=H.reach_boxes())
+    B = 8
+    G = torch.zeros(B, warm.m, dtype=torch.float64, device="cuda")
+    viol = torch.empty(B, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    warm.violation_device(G.data_ptr(), B, viol.data_ptr(), st)  # (the library's code object is loaded by its first launch)
+    p = H.kinova_problem(hip, kinova, keep, N=8, boxes=H.reach_boxes())  # a fresh problem: this is its first call
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    p.violation_device(G.data_ptr(), B, viol.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.isfinite(viol).all()
