@@ -200,15 +200,33 @@ def run_rank(args) -> None:
     from raptor_amd.multistart import shard_range, timed_sweep
 
     rank, local_rank, world = dist_env()
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to file descriptor 1 when its first communicator
+    # is created, so everything written to fd 1 from here on goes to stderr and the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no GPU {local_rank}")
     dist = None
     torch.cuda.set_device(local_rank)
+    rccl_note = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif not args.no_multistart and args.workload == "kinova":
+        # ONE rank: the RCCL leg of the multi-start record still runs (a one-rank group), so that the exchange step is executed code
+        # on every bench run, not only on the driver's multi-GPU node.  A group that cannot be created here is reported, not fatal.
+        try:
+            import torch.distributed as dist  # noqa: F811
+            from raptor_amd.launch import free_port
+
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        except Exception as e:  # noqa: BLE001
+            rccl_note = f"one-rank RCCL group not created: {e}"
+            dist = None
 
     import raptor_amd
     from raptor_amd import _capi as A
@@ -217,7 +235,7 @@ def run_rank(args) -> None:
     hip.init(local_rank)
 
     def barrier():
-        if dist is not None:
+        if dist is not None and world > 1:  # (a one-rank group exists for the multi-start record's collective only)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,7 +278,7 @@ def run_rank(args) -> None:
         elapsed = time.perf_counter() - t0
         n_prof, k0_ms, k1_ms = prob.profile_end()
         per_rank_ms, ranks_seen = [1e3 * elapsed / args.steps], 1
-        if dist is not None:
+        if dist is not None and world > 1:
             mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             allt = torch.empty(world, dtype=torch.float64, device="cuda")
             dist.all_gather_into_tensor(allt, mine)            # RCCL: every rank's own time
@@ -490,7 +508,11 @@ def run_rank(args) -> None:
                 return viol[:Gb.shape[0]]
 
             spinup(lambda: evaluate(Z_all[lo:hi]))
-            r = timed_sweep(evaluate, Z_all, lb, ub, args.steps, args.warmup, sync=torch.cuda.synchronize, violation_fn=violation_native)
+            def violation_into(Gb, out):  # ... written straight into the record that is gathered
+                prob.violation_device(Gb.data_ptr(), Gb.shape[0], out.data_ptr(), stream)
+
+            r = timed_sweep(evaluate, Z_all, lb, ub, args.steps, args.warmup, sync=torch.cuda.synchronize, violation_fn=violation_native,
+                            violation_into=violation_into)
             check_v = violation_native(evaluate(Z_all[lo:hi])).clone()
             from raptor_amd.multistart import violation as violation_torch
             assert torch.equal(check_v, violation_torch(G[:hi - lo], lb, ub)), "raptor_violation_batch differs from the torch formula"
@@ -505,14 +527,19 @@ def run_rank(args) -> None:
                 dist.all_reduce(ev, op=dist.ReduceOp.MAX)
             sweep_ms = 1e3 * r["elapsed_s"] / args.steps
             eval_ms = 1e3 * float(ev.item()) / args.steps
+            split = r.get("split_ms") or {}
             rec[key] = {
                 "problems_total": total, "problems_per_gpu": per, "samples": W.samples, "n": prob.n, "m": prob.m,
                 "value": total * W.samples * args.steps / r["elapsed_s"], "unit": "sample-evals/s",
-                "ms_per_sweep": sweep_ms, "ms_evaluation_only": eval_ms, "ms_record_and_gather": max(sweep_ms - eval_ms, 0.0),
+                "ms_per_sweep": sweep_ms,
+                # HIP events inside the timed sweeps (this rank's stream): evaluation | record | collective
+                "ms_evaluation": split.get("evaluation_ms"), "ms_record": split.get("record_ms"), "ms_gather": split.get("gather_ms"),
+                "ms_record_and_gather": (split.get("record_ms", 0.0) + split.get("gather_ms", 0.0)) if split else None,
+                "ms_evaluation_only_separate_run": eval_ms,
                 "per_rank_ms_per_sweep": [1e3 * x / args.steps for x in r["per_rank_s"]],
                 "ranks_seen_by_rccl": r["ranks_seen"],
                 "gathered_records": int(r["violation"].numel()), "feasible": int(r["feasible"].sum().item()),
-                "collective": "all_gather_into_tensor of one double per problem (RCCL)" if world > 1 else "none (one rank)",
+                "collective": ("all_gather_into_tensor of one double per problem (RCCL" + (")" if world > 1 else ", ONE rank: the leg runs, it moves nothing)")) if dist is not None else "none (no process group)",
                 "scaling": key,
             }
             del Z_all, G, J
@@ -532,9 +559,12 @@ def run_rank(args) -> None:
     if args.workload == "kinova" and not args.no_multistart:
         ms = multistart_record()
         if out is not None:
+            if ms is not None and rccl_note:
+                ms["rccl_note"] = rccl_note
             out["multistart"] = ms
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

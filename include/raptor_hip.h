@@ -293,10 +293,26 @@ int raptor_eval_batch_host(raptor_problem* problem, const double* Z, int B, unsi
  *   sense of Optimizer::eval_g (Optimization/src/Optimizer.cpp:374-378) when d_violation[b] <= constr_viol_tol.
  *   d_G = the [B x m] output of raptor_eval_batch; asynchronous on hip_stream, stream-ordered after the call that wrote d_G.
  *   Allocates and uploads nothing: the bounds are put on the device by the *_problem_create call.
- * A C++ host gathers d_violation (B doubles per rank, padded to ceil(total / world)) with one ncclAllGather: INTEGRATION.md.
+ * A C++ host gathers d_violation (B doubles per rank, padded to ceil(total / world)) with one ncclAllGather: INTEGRATION.md,
+ * or calls raptor_eval_batch_sharded below, which does the three steps.
  */
 int raptor_shard_range(long long total, int world, int rank, long long* first, long long* count);
 int raptor_violation_batch(raptor_problem* problem, const double* d_G, int B, double* d_violation, void* hip_stream);
+
+/*
+ * raptor_eval_batch_sharded: one sweep of a multi-start batch over the ranks of a node (no counterpart in the
+ * reference).  Every rank holds the same d_Z_all [total x n]; this rank (one process per GPU) evaluates its own block
+ * [first, first + count) of raptor_shard_range through raptor_eval_batch (d_G [count x m], d_JAC [count x m x n]: this rank's rows
+ * only, Jacobians stay on the GPU that produced them), writes the per-problem record of raptor_violation_batch into its slot of
+ * d_rec_all and completes d_rec_all [world x per], per = ceil(total / world) (padded slots: 0), with ONE in-place ncclAllGather on
+ * `nccl_comm` -- the path's only exchange.  d_rec_all[r * per + k] = worst bound violation of problem r * per + k on every rank.
+ *   nccl_comm  an ncclComm_t of the caller's RCCL (RCCL's API is NCCL's), created over the `world` ranks.  RCCL is not linked into
+ *              this library: ncclAllGather is looked up in the process at the first call (the caller has loaded librccl.so.1 to
+ *              create the communicator).  NULL is accepted with world == 1 only and skips the collective.
+ * Asynchronous on hip_stream like raptor_eval_batch; the collective is enqueued on the same stream.
+ */
+int raptor_eval_batch_sharded(raptor_problem* problem, const double* d_Z_all, long long total, int world, int rank, unsigned flags,
+                              double* d_G, double* d_JAC, double* d_rec_all, void* nccl_comm, void* hip_stream);
 
 /*
  * raptor_eval_batch plus a per-z report of the dependent-joint root finding (SURVEY.md 8b `int* status`).  The reference

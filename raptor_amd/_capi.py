@@ -232,7 +232,7 @@ EXPORTS = [
 STATUS_NOT_CONVERGED = 1
 STATUS_NONFINITE = 2
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
-DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc", "shard_range", "violation_batch"]
+DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc", "shard_range", "violation_batch", "eval_batch_sharded"]
 
 
 class CApi:
@@ -289,6 +289,7 @@ class CApi:
             f("eval_h_batch_noalloc").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
             f("shard_range").argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
             f("violation_batch").argtypes = [vp, vp, C.c_int, vp, vp]
+            f("eval_batch_sharded").argtypes = [vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_uint, vp, vp, vp, vp, vp]
         self._f = f
 
     # -- helpers -------------------------------------------------------------------------
@@ -618,6 +619,12 @@ class ProblemHandle:
     def eval_device(self, d_Z: int, B: int, flags: int, d_G: int, d_JAC: int, stream: int = 0) -> None:
         """Raw device pointers (ints), asynchronous on ``stream``."""
         self.api.check(self.api.fn("eval_batch")(self.handle, d_Z, B, flags, d_G or None, d_JAC or None, stream or None))
+
+    def eval_sharded_device(self, d_Z_all: int, total: int, world: int, rank: int, flags: int, d_G: int, d_JAC: int, d_rec_all: int,
+                            nccl_comm: int = 0, stream: int = 0) -> None:
+        """raptor_eval_batch_sharded: own block evaluated, per-problem record, ONE ncclAllGather over `nccl_comm` (an ncclComm_t)."""
+        self.api.check(self.api.fn("eval_batch_sharded")(self.handle, d_Z_all, total, world, rank, flags, d_G or None, d_JAC or None,
+                                                         d_rec_all or None, nccl_comm or None, stream or None))
 
     def violation_device(self, d_G: int, B: int, d_violation: int, stream: int = 0) -> None:
         """raptor_violation_batch: worst bound violation per decision vector from the [B x m] rows at d_G (device pointers)."""

@@ -2,6 +2,7 @@
 // Host side only does set-up (constant tables, layout, bounds) and launches; there is NO CPU fallback:
 // every evaluation entry point runs on the GPU or returns RAPTOR_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1933,6 +1934,58 @@ int raptor_violation_batch(raptor_problem* p, const double* d_G, int B, double* 
     hipLaunchKernelGGL(violation_kernel, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, (hipStream_t)stream, d_G, p->d_glb.p, p->d_gub.p,
                        p->layout.m, d_violation);
     HIP_CHECK(hipGetLastError());
+    API_CATCH
+}
+
+// RCCL is resolved from the process at run time (never linked: a host without multi-GPU use must not need librccl):
+// ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t), ncclDouble == 8 (rccl.h)
+namespace {
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_all_gather_fn resolve_nccl_all_gather() {
+    static nccl_all_gather_fn fn = nullptr;
+    if (fn) return fn;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (!sym) {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy the caller created its communicator with
+            if (!h) continue;
+            sym = dlsym(h, "ncclAllGather");
+            if (sym) break;
+        }
+    }
+    if (!sym) throw std::runtime_error("raptor_eval_batch_sharded: ncclAllGather not found in this process (load librccl.so.1 and create the communicator first)");
+    fn = reinterpret_cast<nccl_all_gather_fn>(sym);
+    return fn;
+}
+}  // namespace
+
+int raptor_eval_batch_sharded(raptor_problem* p, const double* d_Z_all, long long total, int world, int rank, unsigned flags,
+                              double* d_G, double* d_JAC, double* d_rec_all, void* nccl_comm, void* stream) {
+    API_TRY
+    if (!p) throw std::invalid_argument("null problem");
+    if (total < 0 || world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("bad shard arguments");
+    if (!nccl_comm && world > 1) throw std::invalid_argument("nccl_comm is null with more than one rank");
+    if (total > 0 && (!d_Z_all || !d_rec_all)) throw std::invalid_argument("null argument");
+    if (!(flags & RAPTOR_EVAL_G) || !d_G) throw std::invalid_argument("the per-problem record needs g: RAPTOR_EVAL_G and d_G");
+    if (total == 0) return RAPTOR_OK;
+    const long long per = (total + world - 1) / world;
+    const long long lo = std::min((long long)rank * per, total), count = std::min(lo + per, total) - lo;
+    if (per > 0x7fffffffLL) throw std::invalid_argument("block too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    double* mine = d_rec_all + (size_t)rank * per;
+    if (count < per) HIP_CHECK(hipMemsetAsync(mine + count, 0, (size_t)(per - count) * sizeof(double), st));  // padding of a short block
+    if (count > 0) {
+        eval_device(*p, d_Z_all + (size_t)lo * p->layout.n, (int)count, flags, d_G, d_JAC, st);
+        if (!p->d_glb.p) throw std::runtime_error("bounds are not on the device");
+        hipLaunchKernelGGL(violation_kernel, dim3((unsigned)count), dim3(RAPTOR_BLOCK), 0, st, d_G, p->d_glb.p, p->d_gub.p,
+                           p->layout.m, mine);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (nccl_comm) {  // in place: this rank's block already sits at recvbuff + rank * per
+        const int rc = resolve_nccl_all_gather()(mine, d_rec_all, (size_t)per, /*ncclDouble*/ 8, nccl_comm, st);
+        if (rc != 0) throw std::runtime_error("ncclAllGather failed with code " + std::to_string(rc));
+    }
+    mark_async(*p, st);
     API_CATCH
 }
 

@@ -36,13 +36,20 @@ def violation(G: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor) -> torch.
 
 def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor,
                      g_ub: torch.Tensor, constr_viol_tol: float = 1e-4, gather_g: bool = False,
-                     group=None, violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+                     group=None, violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                     after_eval_event=None, mid_event=None, workspace: Optional[dict] = None,
+                     violation_into: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Evaluate this rank's block of `Z_all` with `evaluate` (Z_block -> G_block, on this rank's device) and gather
     per-problem records on every rank.
 
     `violation_fn` (G_block -> violation per problem) replaces the torch formula of `violation`, e.g. by the library's own
     kernel (`ProblemHandle.violation_device` = raptor_violation_batch).
+    `violation_into` (G_block, out[n]) writes the record in place instead (no copy); `workspace`: a dict the caller keeps between
+    sweeps, holding the record and gather buffers (a sweep then allocates nothing; the returned tensors are views of them and are
+    overwritten by the next sweep).
+    `after_eval_event` / `mid_event` (optional torch.cuda.Event): recorded on the current stream after the evaluation and after the
+    record, i.e. before the collective.
     Returns (violation[B], feasible[B] (bool), G[B, m] or None), identical on all ranks.
     """
     import torch.distributed as dist
@@ -53,18 +60,34 @@ def evaluate_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: to
     lo, hi = shard_range(B, world, rank)
     per = -(-B // world) if world > 0 else B
     G = evaluate(Z_all[lo:hi].contiguous())
+    if after_eval_event is not None:  # (torch.cuda.Event: splits a sweep into evaluation | record | collective on the device's clock)
+        after_eval_event.record()
     m = g_lb.numel()
     dev = G.device
     # fixed-size record per problem: [violation, g...] padded to the block size so one all_gather suffices
     width = 1 + (m if gather_g else 0)
-    rec = torch.zeros((per, width), dtype=torch.float64, device=dev)
     n = hi - lo
+    key = (per, width, world, str(dev))
+    if workspace is not None and workspace.get("key") == key:  # record and gather buffers of the previous sweep, reused
+        rec, out_buf = workspace["rec"], workspace["out"]
+        if n < per:
+            rec[n:].zero_()
+    else:
+        rec = torch.zeros((per, width), dtype=torch.float64, device=dev)
+        out_buf = torch.empty((world * per, width), dtype=torch.float64, device=dev) if dist.is_initialized() else None
+        if workspace is not None:
+            workspace.update(key=key, rec=rec, out=out_buf)
     if n > 0:
-        rec[:n, 0] = violation_fn(G) if violation_fn is not None else violation(G, g_lb.to(dev), g_ub.to(dev))
+        if violation_into is not None and width == 1:
+            violation_into(G, rec[:n, 0])  # the library's kernel writes the record in place (a contiguous run of n doubles)
+        else:
+            rec[:n, 0] = violation_fn(G) if violation_fn is not None else violation(G, g_lb.to(dev), g_ub.to(dev))
         if gather_g:
             rec[:n, 1:] = G
-    if world > 1:
-        out = torch.empty((world * per, width), dtype=torch.float64, device=dev)
+    if mid_event is not None:
+        mid_event.record()
+    if dist.is_initialized():  # also with ONE rank: the collective is the path's exchange step and runs whenever a group exists
+        out = out_buf
         dist.all_gather_into_tensor(out, rec, group=group)
     else:
         out = rec
@@ -95,7 +118,7 @@ def select_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], cost: Calla
     if n > 0:
         rec[:n, 0] = violation(G, g_lb.to(G.device), g_ub.to(G.device))
         rec[:n, 1] = cost(Zb).to(G.device).reshape(-1)
-    if world > 1:
+    if dist.is_initialized():
         out = torch.empty((world * per, 2), dtype=torch.float64, device=G.device)
         dist.all_gather_into_tensor(out, rec, group=group)
     else:
@@ -111,7 +134,8 @@ def select_sharded(evaluate: Callable[[torch.Tensor], torch.Tensor], cost: Calla
 
 def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.Tensor, g_lb: torch.Tensor, g_ub: torch.Tensor,
                 steps: int, warmup: int, sync: Optional[Callable[[], None]] = None, constr_viol_tol: float = 1e-4, group=None,
-                violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> dict:
+                violation_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                violation_into: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None) -> dict:
     """The multi-start sweep as a measured job: `steps` timed passes of `evaluate_sharded` (own block evaluated, per-problem
     record built, ONE all-gather) between barriers, after `warmup` untimed ones.  `sync` waits for this rank's device
     (torch.cuda.synchronize on a GPU; None on the CPU).  Returns, identically on every rank,
@@ -129,14 +153,29 @@ def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.T
             sync()
 
     out = None
+    ws: dict = {}
     for _ in range(max(warmup, 0)):
-        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn)
+        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn, None, None, ws, violation_into)
+    # the split of a sweep on the device's own clock: events on the current stream before the evaluation, after it, after the
+    # record and after the collective of every timed sweep (a GPU batch only; the CPU rehearsals under gloo have no events)
+    cuda = bool(Z_all.is_cuda)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if cuda else []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn)
+    for k in range(steps):
+        if cuda:
+            evs[k][0].record()
+            out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn, evs[k][1], evs[k][2], ws, violation_into)
+            evs[k][3].record()
+        else:
+            out = evaluate_sharded(evaluate, Z_all, g_lb, g_ub, constr_viol_tol, False, group, violation_fn, None, None, ws, violation_into)
     barrier()
     dt = time.perf_counter() - t0
+    split = None
+    if cuda and steps > 0:
+        split = {"evaluation_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / steps,
+                 "record_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / steps,
+                 "gather_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / steps}
     dev = out[0].device if out is not None else Z_all.device
     mine = torch.tensor([dt], dtype=torch.float64, device=dev)
     one = torch.ones(1, dtype=torch.float64, device=dev)
@@ -148,5 +187,5 @@ def timed_sweep(evaluate: Callable[[torch.Tensor], torch.Tensor], Z_all: torch.T
     else:
         allt = mine
     per_rank = [float(x) for x in allt.cpu()]
-    return {"elapsed_s": max(per_rank), "per_rank_s": per_rank, "ranks_seen": int(round(float(one.item()))),
+    return {"elapsed_s": max(per_rank), "per_rank_s": per_rank, "ranks_seen": int(round(float(one.item()))), "split_ms": split,
             "violation": None if out is None else out[0], "feasible": None if out is None else out[1]}
