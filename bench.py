@@ -368,6 +368,30 @@ def run_rank(args) -> None:
             },
             "kernels_ms": {k: v for k, v in zip(W.kernels, kms) if k},
         }
+        if W.bound.startswith("fp64"):
+            # The headline object carries the BINDING roof ("report both fractions and name the larger as binding"):
+            # for the fused Kinova kernel that is fp64 VALU issue.  achieved = executed VALU wave-instructions of one launch (the
+            # committed SQ_INSTS_VALU pass of this same command) x 128 flops -- every VALU wave-instruction priced as one 64-lane fp64
+            # FMA, the most a SIMD can retire per issue slot -- over the launch time measured live; peak = the fp64 vector peak.
+            # frac is therefore VALU-busy at the nominal 4 cycles per instruction and 2.4 GHz.  The HBM line moves to `hbm`.
+            v = (out["roofline_fp64"]["valu"] or {}).get("per_kernel") or []
+            ent = next((e for e in v if e["kernel"] == W.pmc_keys[rows_k]), None)
+            hbm = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                   "algorithmic_bytes_per_launch", "algorithmic_bytes_per_sample_eval")}
+            if ent is not None:
+                ach = ent["executed_fp64_tflops_upper_bound"]
+                out["roofline"].update({
+                    "bound": "fp64-valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                    "achieved_definition": "VALU wave-instructions per launch (profiles/pmc_latest.json, SQ_INSTS_VALU) x 64 lanes x 2 flops / "
+                                           "kernel time measured in this run = VALU-busy at the nominal 4 cycles and 2.4 GHz",
+                    "frac_at_measured_issue_rate": ent["valu_busy_at_measured_issue_rate"],
+                    "measured_issue_rate_source": "profiles/r3_valu_rate_probe.txt: an fp64 wave-instruction costs its SIMD 5.7 / 5.0 / 4.7 "
+                                                  "shader cycles at 2 / 3 / 4 wavefronts per SIMD with the shader clock itself measured at "
+                                                  "2.2-2.3 GHz under sustained fp64 FMA issue (clock64 against s_memrealtime in the same launch)",
+                    "hbm": hbm,
+                })
+            else:
+                out["roofline"]["note"] = "no PMC record of this kernel beside the run: the fp64-valu fraction cannot be formed, the HBM line stands in"
         if not args.no_latency:
             out.update(latency_records(prob, Z, G, J, flags, stream))
         if world == 1 and cpu_seconds > 0:
@@ -615,15 +639,18 @@ def pmc_valu(W, kms):
         # profiles/r2f_valu_rate_probe.txt), in 2.4 GHz cycles per wave-instruction and SIMD: 8.3 / 5.9 / 5.3 / 5.0 at 1 / 2 / 3 / >= 4
         # wavefronts per SIMD
         out.append({"kernel": key, "valu_wave_instructions": ent["SQ_INSTS_VALU"], "valu_busy": ent["SQ_INSTS_VALU"] * 4 / simd_cycles,
-                    "valu_busy_at_measured_issue_rate": {"2_waves_per_simd": ent["SQ_INSTS_VALU"] * 5.9 / simd_cycles,
-                                                         "3_waves_per_simd": ent["SQ_INSTS_VALU"] * 5.3 / simd_cycles,
-                                                         "4_or_more": ent["SQ_INSTS_VALU"] * 5.0 / simd_cycles},
+                    # r3 probe: 2.40 / 2.23 / 2.15 ns per fp64 wave-instruction and SIMD at 2 / 3 / 4 wavefronts per SIMD (wall time)
+                    "valu_busy_at_measured_issue_rate": {"2_waves_per_simd": ent["SQ_INSTS_VALU"] * 2.40e-9 / (1024 * ms * 1e-3),
+                                                         "3_waves_per_simd": ent["SQ_INSTS_VALU"] * 2.23e-9 / (1024 * ms * 1e-3),
+                                                         "4_or_more": ent["SQ_INSTS_VALU"] * 2.15e-9 / (1024 * ms * 1e-3)},
                     "executed_fp64_tflops_upper_bound": ent["SQ_INSTS_VALU"] * 64 * 2 / (ms * 1e-3) / 1e12})
     return {"per_kernel": out, "stale": _pmc_stale(),
-            "note": "valu_busy prices a wave-instruction at the nominal 4 cycles at 2.4 GHz; the measured issue interval of fp64 VALU "
-                    "instructions is 5.0 such cycles at >= 4 wavefronts per SIMD, 5.3 at 3 and 5.9 at 2 (profiles/r2f_valu_rate_probe.txt; "
-                    "the figures assume every instruction is fp64, so values above 1 mean part of the mix is cheaper); kinova_fused_kernel "
-                    "runs at 3 wavefronts per SIMD (11 per CU by LDS), the legged record kernels at 2"} if out else None
+            "note": "valu_busy prices a wave-instruction at the nominal 4 cycles at 2.4 GHz; measured (profiles/r3_valu_rate_probe.txt, "
+                    "clock measured in the launch): an fp64 VALU wave-instruction occupies its SIMD for 2.40 / 2.23 / 2.15 ns at 2 / 3 / 4 "
+                    "wavefronts per SIMD (5.7 / 5.0 / 4.7 cycles of a shader clock that itself sits at 2.2-2.3 GHz under fp64 FMA load), "
+                    "a 32-bit one for 1.6 ns (profiles/r3_valu32_rate_probe.txt); the figures price every instruction as fp64, so values "
+                    "above 1 mean part of the mix is cheaper; kinova_fused_kernel runs at 3 wavefronts per SIMD, the legged record "
+                    "kernels at 2; v_mfma_f64_16x16x4_f64 sustains 26.9 ns per 2048 flops and SIMD = 78 TFLOP/s at an undisturbed 2.39 GHz"} if out else None
 
 
 def _cpu_cores():

@@ -103,6 +103,10 @@ struct DevLegged {
     unsigned long long path8[RAPTOR_LEG_MAX_BODIES][3];     // path[g][0 .. depth-1], one byte each
     unsigned long long col_pack[RAPTOR_LEG_MAX_IND][2];     // col_supp_*[t][0..7], 16 bits each, flag = entry valid
     int flat_n, flat[64];                                   // all (column, support joint) pairs in column order, flag = last of its column
+    // world kinematics by pointer doubling (legged_kernel.h phase A): per body, for round r = 0..4, its ancestor 2^r levels up
+    // (the root included) as 5 bits + a valid bit, 6 bits per round; nrounds = rounds needed for the deepest body
+    unsigned jump_pk[RAPTOR_LEG_MAX_BODIES];
+    int nrounds;
     int ind_ndep[RAPTOR_LEG_MAX_IND];         // dependent loop joints of independent joint t
     int ind_dep_body[RAPTOR_LEG_MAX_IND][6];
     int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)

@@ -154,8 +154,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int gend = has_body ? Q->body_end[gb] : LG;
     // tables this lane walks later, fetched now: inside the loops a dependent global load per step is what the two wavefronts
     // per SIMD cannot hide
-    unsigned long long pcur = Q->path8[gb][0];
-    const unsigned long long pnext1 = Q->path8[gb][1], pnext2 = Q->path8[gb][2];
     const double arm_j = has_joint ? M->armature[jnt] : 0.0, damp_j = has_joint ? M->damping[jnt] : 0.0;
 
     // ---- phase 0: this body's joint value, rates, chain-rule weights towards the independent columns, sincos ----
@@ -227,10 +225,16 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             w1[2] = lr[4] * xdda + lr[5] * xddb + lr[7] * xda * xda + 2.0 * lr[8] * xda * xdb + lr[9] * xdb * xdb;
         }
     }
+    // local transform across this joint in the direction from the foot to this body:
+    //   forward joint  R' = R (plR Rq),   o' = o + R plp,   axis = R (plR e) = R' (X^T plR e),   joint origin o'
+    //   reversed joint R' = R (plR Rq)^T, o' = o - R' plp,  axis = -R' (plR e),                  joint origin o = o' + R' plp
+    // i.e. with (X, t) the step R' = R X, o' = o + R t, the world axis and joint origin follow from the body's OWN world pose and
+    // two constant vectors c_ax, c_o -- no parent pose is needed.
+    M3 Xl;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Xl.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 tl = v3(0, 0, 0), c_ax = v3(0, 0, 0), c_o = v3(0, 0, 0);
     if (has_joint) {
-        // local transform across this joint in the direction of the walk (foot -> this body), so that the walk below is
-        // branch free:  forward joint  R' = R (plR Rq),  o' = o + R plp,         axis = R (plR e),   joint origin o'
-        //               reversed joint R' = R (plR Rq)^T, o' = o - R' plp,       axis = -R e,        joint origin o
         sincos_joint(q, &sq, &cq);
         M3 P;
 #pragma unroll
@@ -241,56 +245,89 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         SV sj;
         joint_world(M->jtype[jnt], q, cq, sq, P, X, dummy, sj);  // X = plR Rq(q), sj.a = signed axis in the parent link frame
         const bool rev = Q->body_rev[gb] != 0;
-        V3 t = pl, ax = sj.a;
+        M3 Xt;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Xt.m[3 * r + c] = X.m[3 * c + r];
         if (rev) {
-            M3 Xt;
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) Xt.m[3 * r + c] = X.m[3 * c + r];
-            X = Xt;
-            t = -mul(X, pl);
-            ax = -mul(X, sj.a);
+            Xl = Xt;
+            tl = -mul(Xt, pl);
+            c_ax = -sj.a;
+            c_o = pl;
+        } else {
+            Xl = X;
+            tl = pl;
+            c_ax = mul(Xt, sj.a);
         }
-        double* x = sl + LL::V + g * LEG_LOC;
+    } else if (g == 0) {  // the root body: the planted foot's world pose
 #pragma unroll
-        for (int k = 0; k < 9; k++) x[k] = X.m[k];
-        x[9] = t.x; x[10] = t.y; x[11] = t.z;
-        x[12] = ax.x; x[13] = ax.y; x[14] = ax.z;
-        x[15] = qd; x[16] = qdd; x[17] = rev ? 1.0 : 0.0;
+        for (int k = 0; k < 9; k++) Xl.m[k] = Q->R0[k];
+        tl = v3(Q->o0[0], Q->o0[1], Q->o0[2]);
     }
-    wave_sync();
-    LEG_PHASE_END(1, q + qd + qdd + sq + cq + w0[0] + w0[1] + w0[2] + w1[0] + w1[1] + w1[2])
+    LEG_PHASE_END(1, q + qd + qdd + sq + cq + w0[0] + w0[1] + w0[2] + w1[0] + w1[1] + w1[2] + Xl.m[0] + tl.x)
 
-    // ---- phase A: world-frame kinematics from the planted foot out to this body (per-lane path) ----
-    M3 Rw;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rw.m[k] = Q->R0[k];
-    V3 ow = v3(Q->o0[0], Q->o0[1], Q->o0[2]);
-    SV vA = sv_zero(), vprevA = sv_zero();
-    const SV a0 = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
-    SV aA = a0;
-    SV s = sv_zero();
-    const int depth = has_body ? Q->body_depth[gb] : 0;
+    // ---- phase A: world-frame kinematics by pointer doubling over the tree (round 3; rounds 1-2 walked every lane's own root path,
+    // up to 15 dependent steps of ~75 instructions for Digit).  After round r a lane holds the transform / velocity sum / acceleration
+    // sum over the last 2^(r+1) bodies of its root path: T_g <- T_anc(g, 2^r) o T_g through an exchange area in LDS, ceil(log2(depth + 1))
+    // rounds (4 for Digit).  v_g = sum s_k qd_k and a_g = a0 + sum (s_k qdd_k + (v_k x s_k) qd_k) are path sums of per-body terms
+    // (v_parent x s_k qd_k = v_k x s_k qd_k since s x s = 0). ----
+    const unsigned jumps = has_body ? Q->jump_pk[gb] : 0u;
+    const int nrounds = Q->nrounds;
+    double* const xch = sl + LL::V + g * LEG_LOC;  // this lane's exchange slot (18 doubles, 16-byte aligned)
+    M3 Rw = Xl;
+    V3 ow = tl;
 #pragma unroll 1
-    for (int d = 0; d < depth; d++) {
-        const double* x = sl + LL::V + (int)(pcur & 255ull) * LEG_LOC;
-        pcur >>= 8;
-        if (d == 7) pcur = pnext1;
-        if (d == 15) pcur = pnext2;
-        const M3 R = mul(Rw, x);
-        const V3 o = ow + mul(Rw, v3(x[9], x[10], x[11]));
-        const V3 axw = mul(Rw, v3(x[12], x[13], x[14]));
-        const V3 oj = (x[17] != 0.0) ? ow : o;
-        s = SV{axw, cross(oj, axw)};
-        const SV sqd = s * x[15];
-        vprevA = vA;
-        aA = aA + s * x[16] + crm(vA, sqd);
-        vA = vA + sqd;
-        Rw = R;
-        ow = o;
+    for (int r = 0; r < nrounds; r++) {
+        v2d_t* xw = reinterpret_cast<v2d_t*>(xch);
+        xw[0] = v2d_t{Rw.m[0], Rw.m[1]}; xw[1] = v2d_t{Rw.m[2], Rw.m[3]}; xw[2] = v2d_t{Rw.m[4], Rw.m[5]};
+        xw[3] = v2d_t{Rw.m[6], Rw.m[7]}; xw[4] = v2d_t{Rw.m[8], ow.x}; xw[5] = v2d_t{ow.y, ow.z};
+        wave_sync();
+        const unsigned j = jumps >> (6 * r);
+        const bool take = (j & 32u) != 0;
+        const v2d_t* xr = reinterpret_cast<const v2d_t*>(sl + LL::V + (take ? (int)(j & 31u) : g) * LEG_LOC);
+        v2d_t u[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) u[c] = xr[c];
+        wave_sync();
+        if (take) {
+            const double A[9] = {u[0].x, u[0].y, u[1].x, u[1].y, u[2].x, u[2].y, u[3].x, u[3].y, u[4].x};
+            const V3 ta = v3(u[4].y, u[5].x, u[5].y);
+            M3 Am;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Am.m[k] = A[k];
+            ow = ta + mul(Am, ow);
+            Rw = mul(Am, Rw.m);
+        }
     }
-    const SV sdA = crm(vprevA, s);
+    const V3 axw = mul(Rw, c_ax);
+    const V3 ojw = ow + mul(Rw, c_o);
+    const SV s = has_joint ? SV{axw, cross(ojw, axw)} : sv_zero();
+    SV vA = s * qd;
+#pragma unroll 1
+    for (int r = 0; r < nrounds; r++) {
+        lds_put(xch, vA);
+        wave_sync();
+        const unsigned j = jumps >> (6 * r);
+        const bool take = (j & 32u) != 0;
+        const SV up = lds_sv(sl + LL::V + (take ? (int)(j & 31u) : g) * LEG_LOC);
+        wave_sync();
+        if (take) vA = vA + up;
+    }
+    const SV sdA = crm(vA, s);
+    const SV a0 = SV{v3(0, 0, 0), v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2])};
+    SV aA = (g == 0) ? a0 : (s * qdd + sdA * qd);  // the root body carries the base acceleration -a_grav into every path sum
+#pragma unroll 1
+    for (int r = 0; r < nrounds; r++) {
+        lds_put(xch, aA);
+        wave_sync();
+        const unsigned j = jumps >> (6 * r);
+        const bool take = (j & 32u) != 0;
+        const SV up = lds_sv(sl + LL::V + (take ? (int)(j & 31u) : g) * LEG_LOC);
+        wave_sync();
+        if (take) aA = aA + up;
+    }
+    if (!has_body) aA = a0;
 
     LEG_PHASE_END(2, sv_sum(vA) + sv_sum(aA) + sv_sum(s) + sv_sum(sdA) + Rw.m[0] + Rw.m[4] + Rw.m[8] + Rw.m[1] + Rw.m[5] + Rw.m[6] + ow.x + ow.y + ow.z)
 

@@ -1291,6 +1291,23 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     static_assert(RAPTOR_LEG_MAX_IND <= 15, "flat entry: 4-bit column fields, 15 = none (and the core kernel's packed loop columns)");
     for (int g = 0; g < nb; g++)
         for (int d = 0; d < Q.body_depth[g]; d++) Q.path8[g][d >> 3] |= (unsigned long long)Q.path[g][d] << (8 * (d & 7));
+    {   // pointer-doubling tables of phase A
+        static_assert(RAPTOR_LEG_MAX_DEPTH < 32, "five doubling rounds cover 32 levels");
+        int maxd = 0;
+        for (int g = 0; g < RAPTOR_LEG_MAX_BODIES; g++) Q.jump_pk[g] = 0u;
+        for (int g = 0; g < nb; g++) {
+            const int D = Q.body_depth[g];
+            maxd = std::max(maxd, D);
+            for (int r = 0; r < 5; r++) {
+                const int up = D - (1 << r);  // depth of the ancestor 2^r levels up
+                if (up < 0) continue;
+                const int anc = (up == 0) ? 0 : Q.path[g][up - 1];
+                Q.jump_pk[g] |= ((unsigned)anc | 32u) << (6 * r);
+            }
+        }
+        Q.nrounds = 0;
+        while ((1 << Q.nrounds) < maxd + 1) Q.nrounds++;
+    }
     for (int t = 0; t < ni; t++)
         for (int r = 0; r < Q.col_nsupp[t]; r++) {
             const int k = Q.col_supp_body[t][r];
