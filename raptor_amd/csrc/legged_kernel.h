@@ -811,12 +811,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         double wa[3], wb[3];
         {
             const bool sa = (mode == 2u) ? false : s1;
-#pragma unroll
 #if defined(LEG_F2_PROBE) && LEG_F2_PROBE == 2  // measurement build: no weight shuffles
             for (int c = 0; c < 3; c++) wa[c] = sa ? w1[c] : w0[c];
             if (false) {
 #else
-            for (int c = 0; c < 3; c++) wa[c] = shfl_f2(sa ? w1[c] : w0[c], k);
+            if (sa) {  // a uniform branch, kept a branch (six selects per step otherwise: the row pass is bound by VALU issue)
+                asm volatile("");
+                for (int c = 0; c < 3; c++) wa[c] = shfl_f2(w1[c], k);
+            } else {
+                asm volatile("");
+                for (int c = 0; c < 3; c++) wa[c] = shfl_f2(w0[c], k);
+            }
             if (mode == 2u) {
 #endif
 #pragma unroll
@@ -830,14 +835,19 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const bool anc = has_joint && k > g && k < gend;     // this joint is a strict ancestor of k
             const bool dsc = has_joint && g >= k && g < kend;    // k is this joint or one of its ancestors
             const SV A = anc ? sR : ISR;  // registers: per-lane LDS slots 288 B apart would bank-conflict on 128-bit reads
-            double da = dot(A, P.U1);
-            const double t2 = dot(A, P.U2), t3 = dot(A, P.U3);
-            const double e2 = dot(BtS, P.U1), e3 = dot(BtS, P.U2);
+            // six-term FMA chains (the row pass is bound by VALU issue: 30 instead of 35 instructions for the five products)
+#define DOT6(p_, q_) __builtin_fma((p_).a.x, (q_).a.x, __builtin_fma((p_).a.y, (q_).a.y, __builtin_fma((p_).a.z, (q_).a.z, \
+                     __builtin_fma((p_).l.x, (q_).l.x, __builtin_fma((p_).l.y, (q_).l.y, (p_).l.z * (q_).l.z)))))
+            double da = DOT6(A, P.U1);
+            const double t2 = DOT6(A, P.U2), t3 = DOT6(A, P.U3);
+            const double e2 = DOT6(BtS, P.U1), e3 = DOT6(BtS, P.U2);
+#undef DOT6
             double dv = anc ? t2 : 2.0 * t2 + e2;
             double dq = anc ? t3 : t3 + e3;
-            const double own = (g == k) ? 1.0 : 0.0;  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
-            da += own * arm_j;
-            dv += own * damp_j;
+            if (g == k) {  // ConstrainedInverseDynamics.cpp:144-146 and the armature on the diagonal of M
+                da += arm_j;
+                dv += damp_j;
+            }
             const double rel = (anc || dsc) ? 1.0 : 0.0;
             da *= rel; dv *= rel; dq *= rel;
             if (mode != 1u) {  // set 0
@@ -862,10 +872,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const int it = (int)(set == 0 ? (ent >> 15 & 15u) : (ent >> 19 & 15u));
             if (it == 15) continue;  // uniform
             const double Sq = set == 0 ? Tq : Xq, Sv = set == 0 ? Tv : Xv, Sa = set == 0 ? Ta : Xa;
-            {   // every lane writes its slot (a lane without a joint holds zeros): the projection below reads slot 0 for absent entries
+            {   // every lane writes its slot; a lane without a joint writes exact zeros (selected, not 0 * x: a non-finite vector of
+                // some joint must not reach the actuators that read slot 0 for their absent entries)
                 double* ts = sl + LL::TS + g * LL::TSS;
-                *reinterpret_cast<v2d_t*>(ts) = v2d_t{Sq, Sv};
-                ts[2] = Sa;
+                *reinterpret_cast<v2d_t*>(ts) = v2d_t{has_joint ? Sq : 0.0, has_joint ? Sv : 0.0};
+                ts[2] = has_joint ? Sa : 0.0;
             }
             if (lamrec != nullptr && rc >= 0) {
                 const int nrec = Q->nrec;
@@ -877,7 +888,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 double Rq = Sq, Rv = Sv, Ra = Sa;
                 unsigned dpk = dep_pk, apk = aux_pk;
                 asm volatile("" : "+v"(dpk), "+v"(apk));  // unpacked here, every time: hoisted out of the loop they are ten registers again
-                const int nd_ = (int)(apk & 7u);
                 // all reads in flight together, then selected: a read under `d < ndep` is a divergent branch with its own LDS round trip, six
                 // in a row per column (round 2's form: the projection and its stores were 0.08 of the row pass's 0.30 ms)
                 v2d_t tqv[6];
@@ -889,9 +899,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     ta_[d] = ts[2];
                 }
 #pragma unroll
-                for (int d = 0; d < 6; d++) {
-                    const bool on = d < nd_;
-                    Rq += gdep[d] * (on ? tqv[d].x : 0.0); Rv += gdep[d] * (on ? tqv[d].y : 0.0); Ra += gdep[d] * (on ? ta_[d] : 0.0);
+                for (int d = 0; d < 6; d++) {  // absent entries: body 0's slot (exact zeros, above) times gdep = 0
+                    Rq += gdep[d] * tqv[d].x; Rv += gdep[d] * tqv[d].y; Ra += gdep[d] * ta_[d];
                 }
                 if (it == (int)(apk >> 3 & 15u)) Rq += Kq[0];
                 if (it == (int)(apk >> 7 & 15u)) Rq += Kq[1];
