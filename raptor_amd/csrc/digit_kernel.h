@@ -363,6 +363,13 @@ RD void digit_loops_body(const DevTraj* __restrict__ T, const DevDigit* __restri
         if (iterations != nullptr) atomicMax(iterations + b, iter);
     }
 
+#if defined(DIGIT_LOOPS_STOP) && DIGIT_LOOPS_STOP == 1  // measurement build: Newton only
+    {
+        double* out = loops + ((size_t)e * D->recs_per_sample + L->rec0) * DIGIT_REC;
+        for (int r = 0; r < NY; r++) out[r * DIGIT_REC] = th[r] + lu.a[r][r];
+        return;
+    }
+#endif
     double Y1[NX][NY], U[NX][NY + NX];
 #pragma unroll
     for (int a = 0; a < NX; a++) {
@@ -398,6 +405,11 @@ RD void digit_loops_body(const DevTraj* __restrict__ T, const DevDigit* __restri
     }
     // Y3[(a,b,d)], a <= b <= d, packed aaa, aab, abb, bbb
     double Y3[NT][NY];
+#if defined(DIGIT_LOOPS_STOP) && DIGIT_LOOPS_STOP == 2  // measurement build: no third-order derivatives
+    for (int t = 0; t < NT; t++)
+        for (int r = 0; r < NY; r++) Y3[t][r] = 0.0;
+    if (false)
+#endif
     {
         int t = 0;
 #pragma unroll

@@ -945,12 +945,35 @@ __global__ __launch_bounds__(256) void probe_pattern_kernel(double* __restrict__
     }
 }
 
+// chunk_doubles = -7: the pattern of mode -3 (three pieces + one contiguous customized run per (z, sample pair) item) written by a
+// PERSISTENT grid: `blocks` workgroups walk the 4096 x 7 items of the Digit bench batch in order, item = blockIdx.x, += gridDim.x.
+// What a double-buffered persistent expansion (3-4 workgroups per CU) could reach at best.
+__global__ __launch_bounds__(256) void probe_persistent_kernel(double* __restrict__ p, const long long items) {
+    constexpr int n = 132, M = 1005;
+    for (long long w = blockIdx.x; w < items; w += gridDim.x) {
+        double* zb = p + (w / 7) * (long long)M * n;
+        const int pair = (int)(w % 7);
+        const int rows[3] = {12, 36, 7}, off[3] = {0, 14 * 12, 14 * 48};
+        for (int b = 0; b < 3; b++) {
+            double* dst = zb + (long long)(off[b] + pair * 2 * rows[b]) * n;
+            for (int el = 2 * threadIdx.x; el < 2 * rows[b] * n; el += 512) *reinterpret_cast<double2*>(dst + el) = make_double2(1.0, 2.0);
+        }
+        double* cb = zb + (long long)(14 * 55 + pair * 21) * n;
+        const int nr = min(21, 144 - pair * 21);
+        for (int el = 2 * threadIdx.x; el < nr * n; el += 512) *reinterpret_cast<double2*>(cb + el) = make_double2(1.0, 2.0);
+    }
+}
+
 extern "C" {
 
 int raptor_probe_fill(double* d_p, long long blocks, long long chunk_doubles, void* stream) {
     if (chunk_doubles == -5 || chunk_doubles == -6) {
         if (chunk_doubles == -5) hipLaunchKernelGGL(probe_wide_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p);
         else hipLaunchKernelGGL(probe_wide_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p);
+        return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
+    }
+    if (chunk_doubles == -7) {
+        hipLaunchKernelGGL(probe_persistent_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p, 4096LL * 7);
         return hipGetLastError() == hipSuccess ? RAPTOR_OK : RAPTOR_ERR_HIP;
     }
     if (chunk_doubles == -4) {
