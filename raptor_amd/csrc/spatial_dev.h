@@ -65,7 +65,16 @@ RD SV operator+(SV p, SV q) { return SV{p.a + q.a, p.l + q.l}; }
 RD SV operator-(SV p, SV q) { return SV{p.a - q.a, p.l - q.l}; }
 RD SV operator*(SV p, double s) { return SV{p.a * s, p.l * s}; }
 RD SV sv_zero() { return SV{V3{0, 0, 0}, V3{0, 0, 0}}; }
+#ifdef RAPTOR_DOT_TREE
 RD double dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+#else
+// one chain of six fused multiply-adds (1 multiply + 5 FMA) instead of two three-term products and an add: the kernels are bound by
+// VALU issue, and their 6-vector products are the bulk of the fp64 instructions
+RD double dot(SV p, SV q) {
+    return __builtin_fma(p.a.x, q.a.x, __builtin_fma(p.a.y, q.a.y, __builtin_fma(p.a.z, q.a.z,
+           __builtin_fma(p.l.x, q.l.x, __builtin_fma(p.l.y, q.l.y, p.l.z * q.l.z)))));
+}
+#endif
 // motion x motion   (Spatial.h crm)
 RD SV crm(SV v, SV m) { return SV{cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)}; }
 // motion x* force   (Spatial.h crf)
