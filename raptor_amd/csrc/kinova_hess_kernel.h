@@ -572,7 +572,7 @@ RD int pair_index(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a); } 
 #ifndef H_OCC
 #define H_OCC 2  // waves per SIMD the register allocation must leave room for (w state in LDS: 252 VGPRs, no AGPR copies)
 #endif
-template <bool SPLIT>
+template <bool SPLIT, bool TORQUE>
 __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
@@ -614,7 +614,8 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
 
         // ---- torque rows: this wavefront's seven pairs, lane = sample ----
 #pragma unroll 1
-        for (int it = SPLIT ? (int)blockIdx.y : 0; it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
+        // TORQUE = false: the torque rows are left to kinova_hess_torque_kernel (shared chains), which adds into Hout afterwards
+        for (int it = SPLIT ? (int)blockIdx.y : 0; TORQUE && it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
             const int code = H_PAIR_OF[wave][it];
             const int pa = code >> 3, pb = code & 7;
             Kin<double> k0;
@@ -706,7 +707,11 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
         __syncthreads();  // world-frame tables complete
 
         // ---- obstacle rows: a wavefront per sphere, lane = sample ----
+#ifdef H_MEASURE_NO_OBSTACLES  // measurement stub: the torque phase alone
+        if (false) {
+#else
         if (O > 0) {
+#endif
             double acc[H_PAIRS];
 #pragma unroll
             for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;

@@ -24,6 +24,7 @@
 #include "digit_kernel.h"
 #include "period_kernel.h"
 #include "kinova_hess_kernel.h"
+#include "kinova_hess_torque_kernel.h"
 #include "sphere_rows_kernel.h"
 #include "kinova_hess_blocks_kernel.h"
 #include "digit_constants.h"
@@ -2290,6 +2291,50 @@ int raptor_kinova_eval_objective_host(raptor_problem* p, const double* Z, int B,
     API_CATCH
 }
 
+// Optimizer::eval_h for KinovaOptimizer on the device: obstacle rows (kinova_hessian_kernel<., false>), then the torque rows added by
+// kinova_hess_torque_kernel.  split: seven workgroups per z into part[B][7][28], then the fixed-order sum (few decision vectors).
+static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d_Z, int B, const double* d_obj_factor,
+                                  const double* d_lambda, int tplan, double* part, double* d_H, hipStream_t st) {
+    static const bool pairwalk = getenv("RAPTOR_H_PAIRWALK") != nullptr;  // measurement: the round-2 form (a hyper-dual walk per pair)
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)HT_TOTAL * sizeof(double);
+    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_hess_torque_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kinova_hess_torque_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    if (split) {
+        if (pairwalk)
+            hipLaunchKernelGGL((kinova_hessian_kernel<true, true>), dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
+        else
+            hipLaunchKernelGGL((kinova_hessian_kernel<true, false>), dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
+        HIP_CHECK(hipGetLastError());
+        if (!pairwalk) {
+            hipLaunchKernelGGL(kinova_hess_torque_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_model.p,
+                               p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, part);
+            HIP_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, part, p->d_wsum.p,
+                           d_obj_factor, tplan, B, d_H);
+    } else {
+        if (pairwalk)
+            hipLaunchKernelGGL((kinova_hessian_kernel<false, true>), dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
+        else
+            hipLaunchKernelGGL((kinova_hessian_kernel<false, false>), dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
+        HIP_CHECK(hipGetLastError());
+        if (!pairwalk)
+            hipLaunchKernelGGL(kinova_hess_torque_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_model.p,
+                               p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, d_H);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const double* d_obj_factor, const double* d_lambda, double* d_H,
                         void* stream) {
     API_TRY
@@ -2312,16 +2357,9 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
     static const int h_split_max = getenv("RAPTOR_H_SPLIT_MAX") ? atoi(getenv("RAPTOR_H_SPLIT_MAX")) : 112;  // measured crossover near B = 128
     if (B <= h_split_max) {  // few decision vectors (the Ipopt-driven case is B = 1): seven workgroups per z, then a fixed-order sum
         p->s_hpart.ensure((size_t)std::max(32, B) * 7 * H_PAIRS);
-        hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
-                           p->s_hpart.p);
-        HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, p->s_hpart.p,
-                           p->d_wsum.p, d_obj_factor, tplan, B, d_H);
+        launch_kinova_hessian(p, true, d_Z, B, d_obj_factor, d_lambda, tplan, p->s_hpart.p, d_H, st);
     } else {
-        hipLaunchKernelGGL(kinova_hessian_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan,
-                           d_H);
+        launch_kinova_hessian(p, false, d_Z, B, d_obj_factor, d_lambda, tplan, nullptr, d_H, st);
     }
     HIP_CHECK(hipGetLastError());
     mark_async(*p, (hipStream_t)stream);
@@ -2345,13 +2383,8 @@ int raptor_eval_h_batch_noalloc(raptor_problem* p, const double* d_Z, int B, con
     double* part = scratch_device_address();  // device address of the workspace on the current GPU (hipGetSymbolAddress, cached)
     const int tplan = p->tplan_n < 0 ? 0 : p->tplan_n;
     hipStream_t st = (hipStream_t)stream;
-    // every entry part[b][k][pair], b < B, has exactly one writer in the first kernel: nothing has to start at zero
-    hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                       p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
-    HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, part, p->d_wsum.p,
-                       d_obj_factor, tplan, B, d_H);
-    HIP_CHECK(hipGetLastError());
+    // every entry part[b][k][pair], b < B, is written by the first kernel before the second adds to it: nothing has to start at zero
+    launch_kinova_hessian(p, true, d_Z, B, d_obj_factor, d_lambda, tplan, part, d_H, st);
     // (no ordering event here: this entry point touches none of the problem's scratch, and a caller under stream capture must not
     // have an event of ours captured into its graph)
     API_CATCH
