@@ -24,6 +24,13 @@ struct DevModel {
     double friction[RAPTOR_MAX_NV];
 };
 
+// eval_h torque rows (kinova_hess_torque_kernel.h): the serial chain's constants per link, every link frame re-labelled cyclically so
+// that its joint axis is the third one (a proper rotation).  c[l] = { rows I, J, K of jointPlacement^T in the parent's labels (9),
+// placement translation in the parent's labels (3), mass, lever (3), inertia about the COM xx xy xz yy yz zz (6), joint sign, pad }
+struct DevHessLinks {
+    double c[8][24];
+};
+
 // Trajectory: q_j(t_i) = sum_k coef(k, j) * basis[i][0][k]  (and [1] = d/dt, [2] = d2/dt2 bases).
 // The basis tables depend only on the sample index and are built once on the host with the
 // reference's arithmetic (BezierCurves.cpp:117-141, Polynomials.cpp:54-68).

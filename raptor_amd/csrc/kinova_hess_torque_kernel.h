@@ -16,18 +16,18 @@
 //         V^ab = w0 V^a x J_b,   W^ab = w0 W^a x J_b,   A^ab = (w0 A^a + w1 V^a) x J_b + w0 V^a x Jd_b      (a <= b <= l),
 //     a = b included.  Moving the cross products onto the forces they are multiplied with, a pair's term at a link is five
 //     6-vector products of a covector of chain a with a vector of chain b:
-//         J_b.G^a + Jd_b.G2^a + f^b.W^a + W^b.f^a - V^b.Q^a ,
+//         J_b.G^a + Jd_b.G2^a + f^b.W^a + W^b.f^a - U^a.H^b - U^b.H^a ,
 //         G^a  = -[w0 W^a x* f + (w0 A^a + w1 V^a) x* (I W) + w0 V^a x* c],   G2^a = -w0 V^a x* (I W),
-//         Q^a  = W x* (I V^a) - I (W x V^a),   c = the covector of  W.(u x* I V + V x* I u) = c.u ;
-//   * per link every chain lane leaves (G, G2, J, Jd), then (W, f, Q, V) in its LDS record (two stages over the same 24 doubles),
+//         U^a  = V^a x W,  H^a = I V^a,   c = the covector of  W.(u x* I V + V x* I u) = c.u ;
+//   * per link every chain lane leaves (G, G2, J, Jd), then (W, f, U, H) in its LDS record (two stages over the same 24 doubles),
 //     and the 28 pairs, dealt round-robin in order of b over the eight lanes, read the two records they need: at link l the
 //     (l+1)(l+2)/2 live pairs take ceil(./8) rounds, 14 rounds over the 7 links.  The records are exchanged between lanes of ONE
 //     wavefront only: LDS operations of a wavefront execute in order, no barrier.
 // scripts/proto_hess_shared.py is the numpy statement of this arithmetic (hess_stateless), equal to the hyper-dual form to 1e-15.
 //
 // Frames: every link frame is re-labelled cyclically so that its joint axis is the third one (a proper rotation: cross products are
-// unchanged); the re-labelling is applied to the model constants as they are read (wave-uniform indices, scalar loads), so one
-// instruction stream serves the three axis types.
+// unchanged); the host lays the model constants out in those frames once per problem (DevHessLinks), so one instruction stream
+// serves the three axis types and a link's constants are 23 consecutive doubles of scalar loads.
 //
 // Launch: one workgroup (4 wavefronts) per decision vector, a wavefront takes 8 samples per pass; the sums over samples stay in the
 // pair's lane, then three shuffles, then a fixed-order sum over the four wavefronts: deterministic, no atomics.  The result is ADDED
@@ -37,7 +37,9 @@
 
 #include "kinova_hess_kernel.h"
 
-#define HT_REC 26  // doubles per lane record: 24 used; 52 dwords: 16 consecutive lanes' 128-bit accesses tile the 64 banks
+#ifndef HT_REC
+#define HT_REC 26  // doubles per lane record: 24 used
+#endif
 #define HT_WAVE (64 * HT_REC)
 #define HT_TAB (H_WAVES * HT_WAVE)   // per wavefront: [8 samples][7 joints][q_d, q_dd, cos, sin, mu] + [8 samples][w0, w1, w2, -]
 #define HT_TAB_S 40                  // doubles per sample (35 + 3, padded)
@@ -50,10 +52,13 @@
 
 RD V3 xez(V3 x, double s) { return V3{x.y * s, -x.x * s, 0.0}; }  // x cross (s e_z)
 RD V3 mulE(const double (&E)[9], V3 x) {
-    return V3{E[0] * x.x + E[1] * x.y + E[2] * x.z, E[3] * x.x + E[4] * x.y + E[5] * x.z, E[6] * x.x + E[7] * x.y + E[8] * x.z};
+    return V3{__builtin_fma(E[0], x.x, __builtin_fma(E[1], x.y, E[2] * x.z)), __builtin_fma(E[3], x.x, __builtin_fma(E[4], x.y, E[5] * x.z)),
+              __builtin_fma(E[6], x.x, __builtin_fma(E[7], x.y, E[8] * x.z))};
 }
 RD SV xup(const double (&E)[9], V3 p, SV x) {  // plux(R^T, p) then the joint rotation, as one matrix
-    return SV{mulE(E, x.a), mulE(E, x.l + cross(x.a, p))};
+    const V3 t = V3{__builtin_fma(x.a.y, p.z, __builtin_fma(-x.a.z, p.y, x.l.x)), __builtin_fma(x.a.z, p.x, __builtin_fma(-x.a.x, p.z, x.l.y)),
+                    __builtin_fma(x.a.x, p.y, __builtin_fma(-x.a.y, p.x, x.l.z))};
+    return SV{mulE(E, x.a), mulE(E, t)};
 }
 RD SV ld_sv(const double* p) {  // 16-byte aligned
     const v2d_t a = *reinterpret_cast<const v2d_t*>(p), b = *reinterpret_cast<const v2d_t*>(p + 2), c = *reinterpret_cast<const v2d_t*>(p + 4);
@@ -64,14 +69,36 @@ RD void st_sv(double* p, SV x) {
     *reinterpret_cast<v2d_t*>(p + 2) = v2d_t{x.a.z, x.l.x};
     *reinterpret_cast<v2d_t*>(p + 4) = v2d_t{x.l.y, x.l.z};
 }
-RD int sym6(int i, int j) {  // index of (i, j) in (xx, xy, xz, yy, yz, zz)
-    const int a = i < j ? i : j, b = i < j ? j : i;
-    return (a * (5 - a)) / 2 + b;
+// the same products as spatial_dev.h's crf / crm / apply, written as chains of fused multiply-adds (the kernel is bound by VALU issue)
+#define HT_FMA __builtin_fma
+RD V3 cross_acc(V3 acc, V3 a, V3 b) {  // acc + a x b
+    return V3{HT_FMA(a.y, b.z, HT_FMA(-a.z, b.y, acc.x)), HT_FMA(a.z, b.x, HT_FMA(-a.x, b.z, acc.y)), HT_FMA(a.x, b.y, HT_FMA(-a.y, b.x, acc.z))};
+}
+RD V3 cross_sub(V3 acc, V3 a, V3 b) {  // acc - a x b
+    return V3{HT_FMA(-a.y, b.z, HT_FMA(a.z, b.y, acc.x)), HT_FMA(-a.z, b.x, HT_FMA(a.x, b.z, acc.y)), HT_FMA(-a.x, b.y, HT_FMA(a.y, b.x, acc.z))};
+}
+RD SV crf_acc(SV acc, SV v, SV f) {  // acc + v x* f
+    return SV{cross_acc(cross_acc(acc.a, v.a, f.a), v.l, f.l), cross_acc(acc.l, v.a, f.l)};
+}
+RD SV crf_sub(SV acc, SV v, SV f) {  // acc - v x* f
+    return SV{cross_sub(cross_sub(acc.a, v.a, f.a), v.l, f.l), cross_sub(acc.l, v.a, f.l)};
+}
+RD SV crf0(SV v, SV f) { return SV{cross_acc(cross(v.a, f.a), v.l, f.l), cross(v.a, f.l)}; }
+RD SV crm0(SV v, SV m) { return SV{cross(v.a, m.a), cross_acc(cross(v.a, m.l), v.l, m.a)}; }
+RD SV apply_f(const Inertia& I, SV x) {
+    const V3 l = cross_acc(x.l, x.a, I.c) * I.mass;
+    const V3 n = V3{HT_FMA(I.xx, x.a.x, HT_FMA(I.xy, x.a.y, I.xz * x.a.z)), HT_FMA(I.xy, x.a.x, HT_FMA(I.yy, x.a.y, I.yz * x.a.z)),
+                    HT_FMA(I.xz, x.a.x, HT_FMA(I.yz, x.a.y, I.zz * x.a.z))};
+    return SV{cross_acc(n, I.c, l), l};
+}
+RD SV sv_fma(SV x, double s, SV y) {  // x * s + y
+    return SV{V3{HT_FMA(x.a.x, s, y.a.x), HT_FMA(x.a.y, s, y.a.y), HT_FMA(x.a.z, s, y.a.z)},
+              V3{HT_FMA(x.l.x, s, y.l.x), HT_FMA(x.l.y, s, y.l.y), HT_FMA(x.l.z, s, y.l.z)}};
 }
 
 template <bool SPLIT>
 __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kernel(
-    const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis, const double* __restrict__ wsum,
+    const DevHessLinks* __restrict__ HL, const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis, const double* __restrict__ wsum,
     const DevLayout L, const double* __restrict__ Z, const double* __restrict__ lambda, double* __restrict__ Hout) {
     extern __shared__ __align__(16) double lds[];
     constexpr int NV = 7;
@@ -122,12 +149,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
         __builtin_amdgcn_wave_barrier();
         SV V = sv_zero(), W = sv_zero(), J = sv_zero(), Jd = sv_zero();
         SV A = SV{V3{0.0, 0.0, 0.0}, isval ? v3(M->neg_gravity[0], M->neg_gravity[1], M->neg_gravity[2]) : V3{0.0, 0.0, 0.0}};
-        int pc0 = 0, pc1 = 1, pc2 = 2;  // the parent frame's re-labelling
 #pragma unroll 1
         for (int l = 0; l < NV; l++) {
-            const int jt = M->jtype[l];
-            const double sg = jt < 0 ? -1.0 : 1.0;
-            const int Kx = (jt < 0 ? -jt : jt) - 1, Ix = Kx == 2 ? 0 : Kx + 1, Jx = Ix == 2 ? 0 : Ix + 1;
+            const double* K_ = HL->c[l];  // the link's constants, axis-last frames (device_types.h DevHessLinks)
+            const double sg = K_[22];
             const double* t = tab + l * 5;
             const double vjs = sg * t[0];
             const double w0 = tab[35];
@@ -135,14 +160,11 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
                 double E[9];
                 {
                     const double C = t[2], Sn = sg * t[3];
-                    const double* R = M->plR[l];
-                    const double ri0 = R[pc0 * 3 + Ix], ri1 = R[pc1 * 3 + Ix], ri2 = R[pc2 * 3 + Ix];
-                    const double rj0 = R[pc0 * 3 + Jx], rj1 = R[pc1 * 3 + Jx], rj2 = R[pc2 * 3 + Jx];
-                    E[0] = C * ri0 + Sn * rj0; E[1] = C * ri1 + Sn * rj1; E[2] = C * ri2 + Sn * rj2;
-                    E[3] = C * rj0 - Sn * ri0; E[4] = C * rj1 - Sn * ri1; E[5] = C * rj2 - Sn * ri2;
-                    E[6] = R[pc0 * 3 + Kx]; E[7] = R[pc1 * 3 + Kx]; E[8] = R[pc2 * 3 + Kx];
+                    E[0] = C * K_[0] + Sn * K_[3]; E[1] = C * K_[1] + Sn * K_[4]; E[2] = C * K_[2] + Sn * K_[5];
+                    E[3] = C * K_[3] - Sn * K_[0]; E[4] = C * K_[4] - Sn * K_[1]; E[5] = C * K_[5] - Sn * K_[2];
+                    E[6] = K_[6]; E[7] = K_[7]; E[8] = K_[8];
                 }
-                const V3 p = v3(M->plp[l][pc0], M->plp[l][pc1], M->plp[l][pc2]);
+                const V3 p = v3(K_[9], K_[10], K_[11]);
                 // ---- this lane's chain: X_up, then the joint's own motion on the value lane (CustomizedInverseDynamics.cpp:155-157) ----
                 V = xup(E, p, V); A = xup(E, p, A); W = xup(E, p, W); J = xup(E, p, J); Jd = xup(E, p, Jd);
             }
@@ -161,13 +183,9 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
             __builtin_amdgcn_wave_barrier();
             const SV Vv = ld_sv(vrec), Wv = ld_sv(vrec + 12);
             Inertia Il;
-            {
-                Il.mass = M->mass[l];
-                Il.c = v3(M->lever[l][Ix], M->lever[l][Jx], M->lever[l][Kx]);
-                const double* Ic = M->Ic[l];
-                Il.xx = Ic[sym6(Ix, Ix)]; Il.xy = Ic[sym6(Ix, Jx)]; Il.xz = Ic[sym6(Ix, Kx)];
-                Il.yy = Ic[sym6(Jx, Jx)]; Il.yz = Ic[sym6(Jx, Kx)]; Il.zz = Ic[sym6(Kx, Kx)];
-            }
+            Il.mass = K_[12];
+            Il.c = v3(K_[13], K_[14], K_[15]);
+            Il.xx = K_[16]; Il.xy = K_[17]; Il.xz = K_[18]; Il.yy = K_[19]; Il.yz = K_[20]; Il.zz = K_[21];
             SV fv;
             {
                 const SV Av = ld_sv(vrec + 6);
@@ -185,17 +203,17 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
                     J.a.z = sg;
                     Jd = sv_zero();
                 }
-                fv = apply(Il, Av);
+                fv = apply_f(Il, Av);
             }
             // ---- value-level force quantities (every lane: one instruction stream) ----
-            const SV Hv = apply(Il, Vv);
-            fv = fv + crf(Vv, Hv);
+            const SV Hv = apply_f(Il, Vv);
+            fv = crf_acc(fv, Vv, Hv);
             // ---- stage 1: (G, G2 | J, Jd), signs folded: the pair term subtracts ----
             {
-                const SV IW = apply(Il, Wv);
-                const SV cv = SV{cross(Hv.a, Wv.a) + cross(Hv.l, Wv.l), cross(Hv.l, Wv.a)} - apply(Il, crm(Vv, Wv));
-                const SV X1 = crf(V, IW);
-                const SV G = (crf(W, fv) + crf(A, IW) + crf(V, cv)) * w0 + X1 * tab[36];
+                const SV IW = apply_f(Il, Wv);
+                const SV cn = crf_acc(apply_f(Il, crm0(Vv, Wv)), Wv, Hv);  // minus the covector c
+                const SV X1 = crf0(V, IW);
+                const SV G = sv_fma(crf_sub(crf_acc(crf0(W, fv), A, IW), V, cn), w0, X1 * tab[36]);
                 if (!isval) {
                     st_sv(my, G);
                     st_sv(my + 6, X1 * w0);
@@ -204,6 +222,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            // (lanes whose pair is not live yet sit the round out; making the rounds wave-uniform with a select at the end measured 1 % slower)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int pa = (pairs >> (8 * r)) & 15, pb = (pairs >> (8 * r + 4)) & 15;
@@ -214,16 +233,15 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- stage 2: (W, f, Q | V) ----
+            // ---- stage 2: (W, f | U, H):  U^a.H^b + U^b.H^a,  U = V x W(value),  H = I V ----
             {
-                const SV Hc = apply(Il, V);
-                const SV fc = apply(Il, A) + crf(V, Hv) + crf(Vv, Hc);  // f^a = I A^a + V^a x* I V + V x* I V^a
-                const SV Q = crf(Wv, Hc) - apply(Il, crm(Wv, V));
+                const SV Hc = apply_f(Il, V);
+                const SV fc = crf_acc(crf_acc(apply_f(Il, A), V, Hv), Vv, Hc);  // f^a = I A^a + V^a x* I V + V x* I V^a
                 if (!isval) {
                     st_sv(my, W);
                     st_sv(my + 6, fc);
-                    st_sv(my + 12, Q);
-                    st_sv(my + 18, V);
+                    st_sv(my + 12, crm0(V, Wv));
+                    st_sv(my + 18, Hc);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -233,11 +251,10 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
                 if (pb <= l) {
                     const double* ra = rec_base + pa * HT_REC;
                     const double* rb = rec_base + pb * HT_REC;
-                    acc[r] += (dot(ld_sv(rb + 6), ld_sv(ra)) + dot(ld_sv(rb), ld_sv(ra + 6))) - dot(ld_sv(rb + 18), ld_sv(ra + 12));
+                    acc[r] += (dot(ld_sv(rb + 6), ld_sv(ra)) + dot(ld_sv(rb), ld_sv(ra + 6))) - (dot(ld_sv(rb + 18), ld_sv(ra + 12)) + dot(ld_sv(rb + 12), ld_sv(ra + 18)));
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the next link's records overwrite these
-            pc0 = Ix; pc1 = Jx; pc2 = Kx;
         }
     }
 

@@ -214,6 +214,7 @@ struct raptor_problem {
     DevBuf<DevSpheres> d_spheres;
     DevBuf<DevBox> d_boxes;
     DevBuf<double> s_hpart; // eval_h, split form: partial Hessians [32][7][28]
+    DevBuf<DevHessLinks> d_hlinks;  // eval_h torque rows: per-link constants in axis-last frames (kind 1, 7-joint serial revolute chains)
     DevBuf<DevHessItems> d_hitems;  // eval_h over PiecewiseBezierCurves: the 154 block items dealt to four wavefronts
     DevBuf<double> s_phi;           // ... and the per-sample blocks Phi[chunk][182][N]
     DevBuf<int2> d_hpairs;          // ... and per (c1 <= c2) the columns and the sample range over which both weights are non-zero
@@ -482,6 +483,30 @@ double* scratch_device_address();  // (defined with the allocation-free eval_h e
 // last step of every *_problem_create: what later calls must not have to allocate, upload or look up
 void finish_problem(raptor_problem& p) {
     if (p.kind == 1) (void)scratch_device_address();  // raptor_eval_h_batch_noalloc: this device's workspace address, resolved here
+    if (p.kind == 1 && p.hmodel.nv == 7 && p.hmodel.serial_chain) {  // eval_h: the chain's constants in axis-last link frames
+        bool revolute = true;
+        for (int l = 0; l < 7; l++) revolute = revolute && std::abs(p.hmodel.jtype[l]) >= 1 && std::abs(p.hmodel.jtype[l]) <= 3;
+        if (revolute) {
+            DevHessLinks h{};
+            int pc[3] = {0, 1, 2};  // the parent frame's re-labelling: new axis i = old axis pc[i]
+            for (int l = 0; l < 7; l++) {
+                const DevModel& m = p.hmodel;
+                const int K = std::abs(m.jtype[l]) - 1, I = (K + 1) % 3, J = (K + 2) % 3;
+                const int me[3] = {I, J, K};
+                double* c = h.c[l];
+                for (int r = 0; r < 3; r++)
+                    for (int cc = 0; cc < 3; cc++) c[r * 3 + cc] = m.plR[l][pc[cc] * 3 + me[r]];  // (R^T)[me[r]][pc[cc]]
+                for (int cc = 0; cc < 3; cc++) c[9 + cc] = m.plp[l][pc[cc]];
+                c[12] = m.mass[l];
+                for (int r = 0; r < 3; r++) c[13 + r] = m.lever[l][me[r]];
+                auto sym = [&](int i, int j) { const int a = std::min(i, j), b = std::max(i, j); return m.Ic[l][(a * (5 - a)) / 2 + b]; };
+                c[16] = sym(I, I); c[17] = sym(I, J); c[18] = sym(I, K); c[19] = sym(J, J); c[20] = sym(J, K); c[21] = sym(K, K);
+                c[22] = m.jtype[l] < 0 ? -1.0 : 1.0;
+                for (int r = 0; r < 3; r++) pc[r] = me[r];
+            }
+            p.d_hlinks.upload(&h, 1);
+        }
+    }
     if (!p.g_lb.empty()) {  // raptor_violation_batch reads the bounds on the device; they never change after create
         p.d_glb.upload(p.g_lb.data(), p.g_lb.size());
         p.d_gub.upload(p.g_ub.data(), p.g_ub.size());
@@ -2314,7 +2339,7 @@ static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d
                                p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
         HIP_CHECK(hipGetLastError());
         if (!pairwalk) {
-            hipLaunchKernelGGL(kinova_hess_torque_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_model.p,
+            hipLaunchKernelGGL(kinova_hess_torque_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p, p->d_model.p,
                                p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, part);
             HIP_CHECK(hipGetLastError());
         }
@@ -2329,7 +2354,7 @@ static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d
                                p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
         HIP_CHECK(hipGetLastError());
         if (!pairwalk)
-            hipLaunchKernelGGL(kinova_hess_torque_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_model.p,
+            hipLaunchKernelGGL(kinova_hess_torque_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p, p->d_model.p,
                                p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, d_H);
     }
     HIP_CHECK(hipGetLastError());

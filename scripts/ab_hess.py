@@ -17,7 +17,7 @@ import helpers as H
 
 libs = sys.argv[1:]
 model = raptor_amd.load_urdf(os.path.join(ROOT, "tests", "robots", "kinova.urdf"))
-B, N = 4096, 128
+B, N = int(os.environ.get("AB_B", 4096)), 128
 keep, probs = [], []
 for path in libs:
     api = A.CApi(path, "raptor_")
