@@ -9,23 +9,20 @@
 //     and mu^T tau = sum_l w_l . f_l with w_l the spatial velocity link l would have under joint rates mu
 //     (virtual power), so phi needs only the FORWARD recursion of RNEA: v_l, a_l, w_l, f_l = I a + v x* I v.
 //     pinocchio::ComputeRNEASecondOrderDerivatives' four nv^3 tensors and the dense products of
-//     InverseDynamics.cpp:141-171 are never formed;
-//   * second derivatives by hyper-dual numbers (value, d/dz_a, d/dz_b, d2/dz_a dz_b) carried through the links in
-//     link-local frames (constant inertias).  ArmourBezierCurves is linear in z with a diagonal pq_pz
-//     (ArmourBezierCurves.cpp:147-151): the seeds are (pq_pz, pq_d_pz, pq_dd_pz)(k, k) on joint k = a and k = b; damping,
-//     friction and armature are linear in (q_d, q_dd): no Hessian;
-//   * a WAVEFRONT owns one pair (a <= b), its 64 lanes are 64 time samples.  The pair being wave-uniform, the chain is walked
-//     in three regimes with scalar branches: links below a carry plain values, links a .. b-1 first-order duals in z_a,
-//     links b .. 6 full hyper-duals -- and only those contribute to d2 phi / dz_a dz_b, so forces are formed from link b on.
-//     Past its seeded link a regime multiplies by plain sines / cosines.  84 of the 196 (pair, link) steps are hyper-dual;
-//   * one workgroup (4 wavefronts) per decision vector, 64 samples per pass: trajectory values and sincos once per (sample,
-//     joint) into LDS (sample-minor: conflict-free), the 28 pairs dealt 7 per wavefront by cost; the sum over samples is a
-//     wave reduction, the sum over passes stays with the owning wavefront: deterministic, no atomics;
-//   * obstacle rows (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:206-288, 451-474): a wavefront owns
-//     one sphere (its joint is wave-uniform), lanes = samples: arg-min box with the Jacobian kernel's code and tie rules, the
-//     distance's gradient n and Hessian K = sign/d (P - n n^T) w.r.t. the centre (P = the reference's clamped-axis projector),
-//     then  lambda s^2 (J_a^T K J_b + n . H_ab),  J_c = w_c x (p - o_c),  H_ab = w_a x J_b  (a <= b): the FK Hessian of
-//     ForwardKinematics.cpp:386-402 in closed form from the world-frame joint axes of that sample.
+//     InverseDynamics.cpp:141-171 are never formed.  ArmourBezierCurves is linear in z with a diagonal pq_pz
+//     (ArmourBezierCurves.cpp:147-151); damping, friction and armature are linear in (q_d, q_dd): no Hessian.
+//     That part is kinova_hess_torque_kernel.h (round 3: every derivative chain of a sample walked once).  The hyper-dual
+//     recursion below (first-order and hyper-dual numbers carried through the links in link-local frames) is what
+//     kinova_hess_blocks_kernel.h builds the longer-horizon problem's per-sample blocks from;
+//   * kinova_hessian_kernel here: the obstacle rows and hess_f.  One workgroup (4 wavefronts) per decision vector, 64 samples per
+//     pass: trajectory values and sincos once per (sample, joint) into LDS (sample-minor: conflict-free), world-frame joint axes
+//     and sphere-link poses by the first wavefront, then a wavefront owns one sphere (its joint is wave-uniform), lanes = samples
+//     (KinovaCustomizedConstraints.cpp:117-155, BoxCollisionAvoidance.cpp:206-288, 451-474): arg-min box with the Jacobian
+//     kernel's code and tie rules, the distance's gradient n and Hessian K = sign/d (P - n n^T) w.r.t. the centre (P = the
+//     reference's clamped-axis projector), then  lambda s^2 (J_a^T K J_b + n . H_ab),  J_c = w_c x (p - o_c),  H_ab = w_a x J_b
+//     (a <= b): the FK Hessian of ForwardKinematics.cpp:386-402 in closed form from the world-frame joint axes of that sample.
+//     The 28 sums stay in the sample's lane over the passes; one wave reduction at the end, then a fixed-order sum over the
+//     wavefronts: deterministic, no atomics.
 #ifndef RAPTOR_KINOVA_HESS_KERNEL_H
 #define RAPTOR_KINOVA_HESS_KERNEL_H
 
@@ -566,13 +563,13 @@ __device__ const unsigned char H_PAIR_OF[H_WAVES][7] = {
 RD int pair_index(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a); }  // upper triangle row by row (Optimizer.cpp:531-538)
 
 // SPLIT = false: one workgroup per decision vector (batches).  SPLIT = true: seven workgroups per decision vector
-// (blockIdx.y = slot): each wavefront takes ONE pair and every 28th sphere, the 28 partial sums go to `Hout` =
-// part[B][7][28] and kinova_hessian_reduce_kernel adds them in a fixed order -- the single-problem (Ipopt-driven) case,
-// where one workgroup per z would leave the chip idle.
+// (blockIdx.y = slot): each wavefront takes every 28th sphere, the 28 partial sums go to `Hout` = part[B][7][28],
+// kinova_hess_torque_kernel<true> adds its share of the samples to the same slots and kinova_hessian_reduce_kernel adds the
+// slots in a fixed order -- the single-problem (Ipopt-driven) case, where one workgroup per z would leave the chip idle.
 #ifndef H_OCC
-#define H_OCC 2  // waves per SIMD the register allocation must leave room for (w state in LDS: 252 VGPRs, no AGPR copies)
+#define H_OCC 2  // waves per SIMD the register allocation must leave room for
 #endif
-template <bool SPLIT, bool TORQUE>
+template <bool SPLIT>
 __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const double* __restrict__ basis,
     const double* __restrict__ wsum, const DevSpheres* __restrict__ S, const DevBox* __restrict__ boxes, const DevLayout L,
@@ -590,6 +587,9 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
     const double* z = Z + b * NV;
     const double* lam = lambda + b * (long long)L.m;
     if (lane < 2 * H_PAIRS) lds[HL_ACC + wave * 2 * H_PAIRS + lane] = 0.0;
+    double acc[H_PAIRS];  // obstacle rows: this lane's sample of every pass, this wavefront's spheres
+#pragma unroll
+    for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
 
 #pragma unroll 1
     for (int i0 = 0; i0 < N; i0 += H_CH) {
@@ -599,81 +599,14 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
             const int i = min(i0 + s, N - 1);
             double q, qd, qdd, sq, cq;
             traj_joint(T, basis, z, i, j, q, qd, qdd);
-            sincos(q, &sq, &cq);
+            sincos_joint(q, &sq, &cq);
             double* x = lds + HL_X + (j * 5) * H_CH + s;
             x[0] = qd; x[H_CH] = qdd; x[2 * H_CH] = cq; x[3 * H_CH] = sq; x[4 * H_CH] = q;
-            lds[HL_MU + j * H_CH + s] = (i0 + s < N) ? lam[L.off_tau + i * NV + j] : 0.0;
         }
-        if (tid < 3 * H_CH) {
-            const int s = tid & (H_CH - 1), k = tid >> 6;
-            lds[HL_WS + k * H_CH + s] = wsum[min(i0 + s, N - 1) * 3 + k];
-        }
+        if (tid < H_CH) lds[HL_WS + tid] = wsum[min(i0 + tid, N - 1) * 3];  // pq_pz of the sample
         __syncthreads();
         const bool live = (i0 + lane) < N;
-        const double w0 = lds[HL_WS + lane], w1 = lds[HL_WS + H_CH + lane], w2 = lds[HL_WS + 2 * H_CH + lane];
-
-        // ---- torque rows: this wavefront's seven pairs, lane = sample ----
-#pragma unroll 1
-        // TORQUE = false: the torque rows are left to kinova_hess_torque_kernel (shared chains), which adds into Hout afterwards
-        for (int it = SPLIT ? (int)blockIdx.y : 0; TORQUE && it < (SPLIT ? (int)blockIdx.y + 1 : 7); it++) {
-            const int code = H_PAIR_OF[wave][it];
-            const int pa = code >> 3, pb = code & 7;
-            Kin<double> k0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                k0.va.c[k] = 0.0; k0.vl.c[k] = 0.0; k0.aa.c[k] = 0.0; k0.wa.c[k] = 0.0; k0.wl.c[k] = 0.0;
-                k0.al.c[k] = M->neg_gravity[k];  // base acceleration -a_grav (CustomizedInverseDynamics.cpp:212)
-            }
-#define HX(l, f) lds[HL_X + ((l) * 5 + (f)) * H_CH + lane]
-#define HSG(l) (M->jtype[l] < 0 ? -1.0 : 1.0)
-            int l = 0;
-#pragma unroll 1
-            for (; l < pa; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k0);
-            KinVA<HD> kh;
-            double* ws = lds + HL_WST + wave * 24 * H_CH + lane;  // this lane's column of the wavefront's w state
-#define HPROM(src) \
-    _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { \
-        kh.va.c[i_] = promote(src.va.c[i_], (HD*)nullptr); kh.vl.c[i_] = promote(src.vl.c[i_], (HD*)nullptr); \
-        kh.aa.c[i_] = promote(src.aa.c[i_], (HD*)nullptr); kh.al.c[i_] = promote(src.al.c[i_], (HD*)nullptr); \
-    } \
-    { T3<HD> wa_, wl_; \
-      _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { wa_.c[i_] = promote(src.wa.c[i_], (HD*)nullptr); wl_.c[i_] = promote(src.wl.c[i_], (HD*)nullptr); } \
-      w_store(ws, 0, wa_); w_store(ws, 1, wl_); }
-            if (pa < pb) {
-                Kin<D1> k1 = promote<D1>(k0);
-                {   // l == pa: seeded in z_a
-                    const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
-                    hess_link(M, l, D1{cq, -sq * w0}, sg * D1{sq, cq * w0}, D1{HX(l, 0), w1}, D1{HX(l, 1), w2},
-                              lds[HL_MU + l * H_CH + lane], k1);
-                    l++;
-                }
-#pragma unroll 1
-                for (; l < pb; l++) hess_link(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], k1);
-                HPROM(k1)
-            } else {
-                HPROM(k0)
-            }
-#undef HPROM
-            double phi_ab;
-            {   // l == pb: seeded in z_b (and in z_a on the diagonal)
-                const double cq = HX(l, 2), sq = HX(l, 3), sg = HSG(l);
-                const double da = (pa == pb) ? w0 : 0.0, ea = (pa == pb) ? w1 : 0.0, fa = (pa == pb) ? w2 : 0.0;
-                hess_link_hd(M, l, HD{cq, -sq * da, -sq * w0, -cq * da * w0}, sg * HD{sq, cq * da, cq * w0, -sq * da * w0},
-                             HD{HX(l, 0), ea, w1, 0.0}, HD{HX(l, 1), fa, w2, 0.0}, lds[HL_MU + l * H_CH + lane], kh, ws);
-                phi_ab = hess_power_ab_lds(M, l, kh, ws);
-                l++;
-            }
-#pragma unroll 1
-            for (; l < NV; l++) {
-                hess_link_hd(M, l, HX(l, 2), HSG(l) * HX(l, 3), HX(l, 0), HX(l, 1), lds[HL_MU + l * H_CH + lane], kh, ws);
-                phi_ab += hess_power_ab_lds(M, l, kh, ws);
-            }
-#undef HX
-#undef HSG
-            const double tot = wave_sum(live ? phi_ab : 0.0);
-            if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + H_PAIRS + pair_index(pa, pb)] += tot;
-        }
-        __syncthreads();  // every wavefront is done with its w state: the obstacle tables take the same LDS
+        const double w0 = lds[HL_WS + lane];
 
         // ---- world-frame joint axes / origins and sphere-link poses of every sample (first wavefront, lane = sample) ----
         if (wave == 0 && O > 0) {
@@ -707,27 +640,23 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, H_OCC) void kinova_hessian_kernel(
         __syncthreads();  // world-frame tables complete
 
         // ---- obstacle rows: a wavefront per sphere, lane = sample ----
-#ifdef H_MEASURE_NO_OBSTACLES  // measurement stub: the torque phase alone
-        if (false) {
-#else
         if (O > 0) {
-#endif
-            double acc[H_PAIRS];
-#pragma unroll
-            for (int k = 0; k < H_PAIRS; k++) acc[k] = 0.0;
 #pragma unroll 1
             for (int sp = SPLIT ? wave + H_WAVES * (int)blockIdx.y : wave; sp < ns; sp += SPLIT ? 7 * H_WAVES : H_WAVES) {
                 const double wgt = live ? lam[L.off_obs + (i0 + lane) * ns + sp] * w0 * w0 : 0.0;
                 hess_sphere_terms(lds, lane, S, boxes, O, sp, wgt, acc);
             }
-#pragma unroll
-            for (int k = 0; k < H_PAIRS; k++) {
-                const double tot = wave_sum(acc[k]);
-                if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + k] += tot;
-            }
         }
         __syncthreads();  // the sample tables are rewritten by the next pass
     }
+    if (O > 0) {  // the obstacle sums of this wavefront's spheres over all passes: one reduction over the 64 samples
+#pragma unroll
+        for (int k = 0; k < H_PAIRS; k++) {
+            const double tot = wave_sum(acc[k]);
+            if (lane == 0) lds[HL_ACC + wave * 2 * H_PAIRS + k] = tot;
+        }
+    }
+    __syncthreads();
 
     // ---- the partial sums in a fixed order; hess_f = diag(pq_pz(tplan_n)^2) (KinovaOptimizer.cpp:243-247) ----
     if (tid < H_PAIRS) {

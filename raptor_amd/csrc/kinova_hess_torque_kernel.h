@@ -31,7 +31,7 @@
 //
 // Launch: one workgroup (4 wavefronts) per decision vector, a wavefront takes 8 samples per pass; the sums over samples stay in the
 // pair's lane, then three shuffles, then a fixed-order sum over the four wavefronts: deterministic, no atomics.  The result is ADDED
-// to what kinova_hessian_kernel<., false> (obstacle rows) left in Hout / in the split form's partial slot, on the same stream.
+// to what kinova_hessian_kernel (obstacle rows) left in Hout / in the split form's partial slot, on the same stream.
 #ifndef RAPTOR_KINOVA_HESS_TORQUE_KERNEL_H
 #define RAPTOR_KINOVA_HESS_TORQUE_KERNEL_H
 

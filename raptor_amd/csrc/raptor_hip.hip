@@ -2316,11 +2316,10 @@ int raptor_kinova_eval_objective_host(raptor_problem* p, const double* Z, int B,
     API_CATCH
 }
 
-// Optimizer::eval_h for KinovaOptimizer on the device: obstacle rows (kinova_hessian_kernel<., false>), then the torque rows added by
+// Optimizer::eval_h for KinovaOptimizer on the device: obstacle rows and hess_f (kinova_hessian_kernel), then the torque rows added by
 // kinova_hess_torque_kernel.  split: seven workgroups per z into part[B][7][28], then the fixed-order sum (few decision vectors).
 static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d_Z, int B, const double* d_obj_factor,
                                   const double* d_lambda, int tplan, double* part, double* d_H, hipStream_t st) {
-    static const bool pairwalk = getenv("RAPTOR_H_PAIRWALK") != nullptr;  // measurement: the round-2 form (a hyper-dual walk per pair)
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)HT_TOTAL * sizeof(double);
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
@@ -2331,31 +2330,20 @@ static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d
         attr_set = true;
     }
     if (split) {
-        if (pairwalk)
-            hipLaunchKernelGGL((kinova_hessian_kernel<true, true>), dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
-        else
-            hipLaunchKernelGGL((kinova_hessian_kernel<true, false>), dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
+        hipLaunchKernelGGL(kinova_hessian_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, part);
         HIP_CHECK(hipGetLastError());
-        if (!pairwalk) {
-            hipLaunchKernelGGL(kinova_hess_torque_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p, p->d_model.p,
-                               p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, part);
-            HIP_CHECK(hipGetLastError());
-        }
+        hipLaunchKernelGGL(kinova_hess_torque_kernel<true>, dim3((unsigned)B, 7), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p,
+                           p->d_model.p, p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, part);
+        HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(kinova_hessian_reduce_kernel, dim3((unsigned)((B * H_PAIRS + 63) / 64)), dim3(64), 0, st, part, p->d_wsum.p,
                            d_obj_factor, tplan, B, d_H);
     } else {
-        if (pairwalk)
-            hipLaunchKernelGGL((kinova_hessian_kernel<false, true>), dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
-        else
-            hipLaunchKernelGGL((kinova_hessian_kernel<false, false>), dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
-                               p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
+        hipLaunchKernelGGL(kinova_hessian_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), 0, st, p->d_model.p, p->d_traj.p,
+                           p->d_basis.p, p->d_wsum.p, p->d_spheres.p, p->d_boxes.p, p->layout, d_Z, d_obj_factor, d_lambda, tplan, d_H);
         HIP_CHECK(hipGetLastError());
-        if (!pairwalk)
-            hipLaunchKernelGGL(kinova_hess_torque_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p, p->d_model.p,
-                               p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, d_H);
+        hipLaunchKernelGGL(kinova_hess_torque_kernel<false>, dim3((unsigned)B), dim3(RAPTOR_BLOCK), lds_bytes, st, p->d_hlinks.p,
+                           p->d_model.p, p->d_traj.p, p->d_basis.p, p->d_wsum.p, p->layout, d_Z, d_lambda, d_H);
     }
     HIP_CHECK(hipGetLastError());
 }
