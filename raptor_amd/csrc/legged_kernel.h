@@ -37,6 +37,11 @@
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
+// 16-byte chunk c of a per-joint vector whose chunks are swapped in pairs when sw2 != 0 (chunk c lives at c ^ 1): `base` is the
+// vector's first double (an even chunk), sw2 = 0 or 2 doubles (-2 when `base` itself starts at an odd chunk)
+__device__ __forceinline__ v2d_t* vec_chunk_ptr(double* base, int sw2, int c) {
+    return reinterpret_cast<v2d_t*>(base + 2 * c + ((c & 1) ? -sw2 : sw2));
+}
 
 template <int LG>
 struct LegLds {
@@ -134,6 +139,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const long long e0 = (long long)blockIdx.x * EPB;  // (uniform; < E by the launch grid)
     const long long e = min(e0 + eg, E - 1);
     double* sl = lds + eg * LL::STRIDE;
+    // The sample-evals of a wavefront sit STRIDE doubles apart, a multiple of the 64 banks: a broadcast read of joint k's vector by every
+    // lane group hit the same banks once per group (SQ_LDS_BANK_CONFLICT ~ 1.2 cycles per LDS instruction in round 2).  Odd groups now
+    // keep the 16-byte chunks of the per-joint vector area swapped in pairs (chunk c at c ^ 1): the groups' reads fall on disjoint banks.
+    const int sw2 = (eg & 1) * 2;  // doubles: even chunks move up by it, odd chunks down
     const int N = T->N;
     // one 64-bit division per wavefront (its first sample-eval), then a wrap per lane group: a per-lane e / N, e % N is ~150 VALU
     const long long b0 = e0 / N;
@@ -426,8 +435,14 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const SV cq_ = Ipsi + QdS + HdS + cF;
             if (has_joint) {
                 double* vv = sl + LL::V + g * LEG_VEC;
-                lds_put(vv, s); lds_put(vv + 6, sd); lds_put(vv + 12, psi);
-                lds_put(vv + 18, IS); lds_put(vv + 24, cv); lds_put(vv + 30, cq_);
+                const SV six[6] = {s, sd, psi, IS, cv, cq_};
+#pragma unroll
+                for (int q6 = 0; q6 < 6; q6++) {
+                    const v2d_t c0 = v2d_t{six[q6].a.x, six[q6].a.y}, c1 = v2d_t{six[q6].a.z, six[q6].l.x}, c2 = v2d_t{six[q6].l.y, six[q6].l.z};
+                    *vec_chunk_ptr(vv, sw2, 3 * q6) = c0;
+                    *vec_chunk_ptr(vv, sw2, 3 * q6 + 1) = c1;
+                    *vec_chunk_ptr(vv, sw2, 3 * q6 + 2) = c2;
+                }
             }
         }
         if (is_torso) {  // the torso's twist and acceleration, which the value phase turns into the floating-base coordinates' rates
@@ -675,12 +690,12 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             const double a0 = __shfl(w0[0], k, LG), a1 = __shfl(w0[1], k, LG), a2 = __shfl(w0[2], k, LG);
             const double b0 = __shfl(w1[0], k, LG), b1 = __shfl(w1[1], k, LG), b2 = __shfl(w1[2], k, LG);
             const double g0 = on ? (s1 ? b0 : a0) : 0.0, hv = on ? (s1 ? b1 : a1) : 0.0, hq = on ? (s1 ? b2 : a2) : 0.0;
-            const v2d_t* vk = reinterpret_cast<const v2d_t*>(sl + LL::V + k * LEG_VEC);
+            double* vk = sl + LL::V + k * LEG_VEC;
             v2d_t u[12];
 #pragma unroll
-            for (int c = 0; c < 3; c++) u[c] = vk[c];
+            for (int c = 0; c < 3; c++) u[c] = *vec_chunk_ptr(vk, sw2, c);
 #pragma unroll
-            for (int c = 3; c < 12; c++) u[c] = vk[6 + c];
+            for (int c = 3; c < 12; c++) u[c] = *vec_chunk_ptr(vk, sw2, 6 + c);
             const SV sk = SV{v3(u[0].x, u[0].y, u[1].x), v3(u[1].y, u[2].x, u[2].y)};
             const SV ISk = SV{v3(u[3].x, u[3].y, u[4].x), v3(u[4].y, u[5].x, u[5].y)};
             const SV cvk = SV{v3(u[6].x, u[6].y, u[7].x), v3(u[7].y, u[8].x, u[8].y)};
@@ -779,13 +794,15 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         const bool anc = has_joint && k > g && k < gend;
         // 16-byte reads (the slot, the wavefront's area and the anc offset are all multiples of 16 bytes): ds_read_b128 moves 256 B per
         // LDS clock, the ds_read2_b64 the compiler picks for 8-byte-aligned doubles half of that -- and the LDS is as busy as the VALU here
-        const v2d_t* vk = reinterpret_cast<const v2d_t*>(sl + LL::V + k * LEG_VEC + (anc ? 18 : 0));
+        // (the second half starts at chunk 9, an odd one: the pair swap changes direction with `anc`)
+        double* vk = sl + LL::V + k * LEG_VEC + (anc ? 18 : 0);
+        const int swk = anc ? -sw2 : sw2;
         v2d_t u[9];
 #if defined(LEG_F2_PROBE) && LEG_F2_PROBE == 3  // measurement build: no vector reads
         for (int c = 0; c < 9; c++) u[c] = v2d_t{s.a.x + c, IS.l.y + k};
 #else
 #pragma unroll
-        for (int c = 0; c < 9; c++) u[c] = vk[c];
+        for (int c = 0; c < 9; c++) u[c] = *vec_chunk_ptr(vk, swk, c);
 #endif
         P.U1 = SV{v3(u[0].x, u[0].y, u[1].x), v3(u[1].y, u[2].x, u[2].y)};
         P.U2 = SV{v3(u[3].x, u[3].y, u[4].x), v3(u[4].y, u[5].x, u[5].y)};
@@ -796,9 +813,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // the value phase's and F1's live registers
     SV sR = sv_zero(), ISR = sv_zero();
     if (has_joint) {
-        const double* own = sl + LL::V + g * LEG_VEC;
-        sR = lds_sv(own);
-        ISR = lds_sv(own + 18);
+        double* own = sl + LL::V + g * LEG_VEC;
+        const v2d_t o0 = *vec_chunk_ptr(own, sw2, 0), o1 = *vec_chunk_ptr(own, sw2, 1), o2 = *vec_chunk_ptr(own, sw2, 2);
+        const v2d_t o9 = *vec_chunk_ptr(own, sw2, 9), o10 = *vec_chunk_ptr(own, sw2, 10), o11 = *vec_chunk_ptr(own, sw2, 11);
+        sR = SV{v3(o0.x, o0.y, o1.x), v3(o1.y, o2.x, o2.y)};
+        ISR = SV{v3(o9.x, o9.y, o10.x), v3(o10.y, o11.x, o11.y)};
     }
     double Tq = 0.0, Tv = 0.0, Ta = 0.0, Xq = 0.0, Xv = 0.0, Xa = 0.0;
     auto f2_step = [&](const int idx, const F2Ops& P) {

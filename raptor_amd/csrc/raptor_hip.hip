@@ -2320,6 +2320,7 @@ int raptor_kinova_eval_objective_host(raptor_problem* p, const double* Z, int B,
 // kinova_hess_torque_kernel.  split: seven workgroups per z into part[B][7][28], then the fixed-order sum (few decision vectors).
 static void launch_kinova_hessian(raptor_problem* p, bool split, const double* d_Z, int B, const double* d_obj_factor,
                                   const double* d_lambda, int tplan, double* part, double* d_H, hipStream_t st) {
+    if (p->d_hlinks.p == nullptr) throw unsupported_error("eval_h kernel: 7-joint serial chains of revolute joints only");
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)HT_TOTAL * sizeof(double);
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
