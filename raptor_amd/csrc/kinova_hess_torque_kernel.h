@@ -40,7 +40,11 @@
 #ifndef HT_REC
 #define HT_REC 26  // doubles per lane record: 24 used
 #endif
-#define HT_WAVE (64 * HT_REC)
+#ifndef HT_GPAD
+#define HT_GPAD 8  // doubles between the record blocks of two samples: block stride = 432 dwords = 48 mod 64 banks (0 / 4 / 16 doubles: 1.42 / 1.43 / 1.68 ms, 8: 1.385)
+#endif
+#define HT_GROUP (8 * HT_REC + HT_GPAD)
+#define HT_WAVE (8 * HT_GROUP)
 #define HT_TAB (H_WAVES * HT_WAVE)   // per wavefront: [8 samples][7 joints][q_d, q_dd, cos, sin, mu] + [8 samples][w0, w1, w2, -]
 #define HT_TAB_S 40                  // doubles per sample (35 + 3, padded)
 #define HT_TAB_WAVE (8 * HT_TAB_S)
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(RAPTOR_BLOCK, HT_OCC) void kinova_hess_torque_kerne
     const int N = T->N;
     const double* z = Z + b * NV;
     const double* lam = lambda + b * (long long)L.m;
-    double* rec_base = lds + wave * HT_WAVE + (lane & ~7) * HT_REC;
+    double* rec_base = lds + wave * HT_WAVE + grp * HT_GROUP;
     double* my = rec_base + c * HT_REC;
     const double* vrec = rec_base + 7 * HT_REC;
     double* tab = lds + HT_TAB + wave * HT_TAB_WAVE + grp * HT_TAB_S;
