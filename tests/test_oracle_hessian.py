@@ -118,3 +118,14 @@ def test_no_obstacles_and_errors(oracle, kinova):
     pid = H.id_problem(oracle, kinova, keep)
     with pytest.raises(A.RaptorError):
         pid.eval_h_host(np.zeros(pid.n), np.zeros(pid.m))  # enable_hessian is false (Optimizer.cpp:513-515)
+
+
+def test_shared_chain_form_of_the_torque_hessian():
+    """numpy statement of the arithmetic of kinova_hess_torque_kernel (scripts/proto_hess_shared.py: value chain and seven first-order
+    chains walked once, the mixed second-order parts as cross products with the carried joint axes) against the hyper-dual recursion
+    the oracle and the round-2 kernel use: an independent formulation of d2(mu^T tau)/dz_a dz_b, equal to rounding."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import proto_hess_shared
+    assert proto_hess_shared.run(trials=3) < 1e-12
