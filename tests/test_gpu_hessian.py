@@ -80,6 +80,25 @@ def test_eval_h_both_launch_forms(oracle, hip, kinova):
     assert np.array_equal(ph.eval_h_host(Z[3:4], lam[3:4], 1.0), Hs[3:4])  # deterministic, independent of the batch around it
 
 
+@pytest.mark.parametrize("N", [7, 9, 33, 65, 127])
+def test_eval_h_sample_counts(oracle, hip, kinova, N):
+    """The torque kernel deals samples in groups of 8 over four wavefronts (and over seven workgroups in the small-batch form), the
+    obstacle kernel in passes of 64: sample counts on both sides of every boundary, in both launch forms, against the oracle."""
+    po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=N, boxes=H.reach_boxes()))
+    rng = np.random.default_rng(100 + N)
+    for p in (po, ph):
+        p.set_objective(np.zeros(7), N // 2)
+    for B in (2, 115):
+        Z = rng.uniform(-1, 1, (B, 7))
+        lam = rng.uniform(-1, 1, (B, po.m))
+        of = rng.uniform(0.5, 1.5, B)
+        Hh = ph.eval_h_host(Z, lam, of)
+        check(Hh[:2], po.eval_h_host(Z[:2], lam[:2], of[:2]), 1e-11)
+        if B > 112:  # the rest of the batch form against the split form of the same z
+            Hs = np.concatenate([ph.eval_h_host(Z[k:k + 50], lam[k:k + 50], of[k:k + 50]) for k in range(0, B, 50)])
+            check(Hh, Hs, 1e-12)
+
+
 def test_eval_h_inside_boxes(oracle, hip, kinova):
     """Every sphere inside an obstacle: the nearest-face branch (BoxCollisionAvoidance.cpp:252-274), negative distances, one clamped
     axis; the first-minimum face / box rules must pick the same face as the oracle for the values to agree."""
