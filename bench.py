@@ -599,12 +599,16 @@ def _pmc_file():
 
 
 def _pmc_stale():
-    """True when a kernel source is newer than the committed counter file (the counters then describe older code)."""
+    """True when a source of the profiled kernels differs from what the committed counter file was collected on (by content:
+    the file lists the SHA-256 of those sources; modification times do not survive a checkout)."""
+    import hashlib
     try:
-        t = os.path.getmtime(_pmc_file())
+        want = json.load(open(_pmc_file())).get("sources_sha256")
+        if not want:
+            return True
         src = os.path.join(ROOT, "raptor_amd", "csrc")
-        return any(os.path.getmtime(os.path.join(src, f)) > t for f in os.listdir(src))
-    except OSError:
+        return any(hashlib.sha256(open(os.path.join(src, f), "rb").read()).hexdigest() != h for f, h in want.items())
+    except (OSError, ValueError):
         return True
 
 

@@ -23,5 +23,12 @@ for arg in sys.argv[2:]:
             ent[ctr + "_bytes"] = val * 1024
         else:
             ent[ctr] = val
+# the sources of the kernels these counters describe, by content: bench.py warns when one of them has changed since
+import hashlib
+import os
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raptor_amd", "csrc")
+out["sources_sha256"] = {f: hashlib.sha256(open(os.path.join(src, f), "rb").read()).hexdigest()
+                         for f in ("kinova_kernel.h", "legged_kernel.h", "period_kernel.h", "digit_kernel.h", "spatial_dev.h", "kernels.h",
+                                   "device_types.h")}
 json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
 print("\n".join(k for k in out if ":" in k))
