@@ -2368,7 +2368,7 @@ int raptor_eval_h_batch(raptor_problem* p, const double* d_Z, int B, const doubl
         if (std::abs(p->hmodel.jtype[l]) > 3) throw unsupported_error("eval_h kernel: revolute joints only");
     const int tplan = p->tplan_n < 0 ? 0 : p->tplan_n;
     hipStream_t st = (hipStream_t)stream;
-    static const int h_split_max = getenv("RAPTOR_H_SPLIT_MAX") ? atoi(getenv("RAPTOR_H_SPLIT_MAX")) : 112;  // measured crossover near B = 128
+    static const int h_split_max = getenv("RAPTOR_H_SPLIT_MAX") ? atoi(getenv("RAPTOR_H_SPLIT_MAX")) : 192;  // measured crossover near B = 210 (round 3 kernels; 128 in round 2)
     if (B <= h_split_max) {  // few decision vectors (the Ipopt-driven case is B = 1): seven workgroups per z, then a fixed-order sum
         p->s_hpart.ensure((size_t)std::max(32, B) * 7 * H_PAIRS);
         launch_kinova_hessian(p, true, d_Z, B, d_obj_factor, d_lambda, tplan, p->s_hpart.p, d_H, st);

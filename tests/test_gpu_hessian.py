@@ -64,11 +64,11 @@ def test_eval_h_matches_oracle(oracle, hip, kinova, kinova_friction, gripper, fr
 
 
 def test_eval_h_both_launch_forms(oracle, hip, kinova):
-    """B <= 112 runs seven workgroups per z plus a fixed-order sum, larger batches one workgroup per z: same numbers, and a z
+    """B <= 192 runs seven workgroups per z plus a fixed-order sum, larger batches one workgroup per z: same numbers, and a z
     evaluated in either form gives bit-identical partial sums order-independently of its neighbours."""
     po, ph, keep = both(oracle, hip, lambda api, k: H.kinova_problem(api, kinova, k, N=70, boxes=H.reach_boxes()))  # two passes, ragged
     rng = np.random.default_rng(41)
-    B = 120
+    B = 200
     Z = rng.uniform(-1, 1, (B, 7))
     lam = rng.uniform(-1, 1, (B, po.m))
     po.set_objective(np.zeros(7), 3)
@@ -88,13 +88,13 @@ def test_eval_h_sample_counts(oracle, hip, kinova, N):
     rng = np.random.default_rng(100 + N)
     for p in (po, ph):
         p.set_objective(np.zeros(7), N // 2)
-    for B in (2, 115):
+    for B in (2, 200):
         Z = rng.uniform(-1, 1, (B, 7))
         lam = rng.uniform(-1, 1, (B, po.m))
         of = rng.uniform(0.5, 1.5, B)
         Hh = ph.eval_h_host(Z, lam, of)
         check(Hh[:2], po.eval_h_host(Z[:2], lam[:2], of[:2]), 1e-11)
-        if B > 112:  # the rest of the batch form against the split form of the same z
+        if B > 192:  # the rest of the batch form against the split form of the same z
             Hs = np.concatenate([ph.eval_h_host(Z[k:k + 50], lam[k:k + 50], of[k:k + 50]) for k in range(0, B, 50)])
             check(Hh, Hs, 1e-12)
 
