@@ -757,9 +757,12 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     // go to a side stream -- their loop part beside the core kernel, the block itself beside the expansion (disjoint rows out, the
     // same records in) -- and join before this call's last launch returns the stream to the caller.
     static const bool no_fork = std::getenv("RAPTOR_NO_FORK") != nullptr;
-    static const long long fork_max = std::getenv("RAPTOR_FORK_MAX") ? std::atoll(std::getenv("RAPTOR_FORK_MAX")) : 512;
+    // Re-measured in round 3 (scripts/fork_sweep.sh, scripts/fork_latency.sh): with Digit's closed loops the fork wins from one problem
+    // (172 -> 167 us) to 1024 problems (0.632 -> 0.619 ms per step) and loses at 4096 (2.05 -> 2.08 ms); Talos / G1 have no loop
+    // kernels to run beside the core kernel and lose ~10 us at every size (one G1 problem: 87.6 us forked, 77.5 us on one stream).
+    static const long long fork_max = std::getenv("RAPTOR_FORK_MAX") ? std::atoll(std::getenv("RAPTOR_FORK_MAX")) : 16384;
     static const bool fork_forced = std::getenv("RAPTOR_FORK_MAX") != nullptr;  // experiments: also under per-kernel timing
-    const bool fork = !no_fork && p.period_rows && jac && B > 0 && E <= fork_max && (between == nullptr || fork_forced);
+    const bool fork = !no_fork && (p.has_digit || fork_forced) && p.period_rows && jac && B > 0 && E <= fork_max && (between == nullptr || fork_forced);
     if (fork) {
         if (p.side == nullptr) {
             HIP_CHECK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
