@@ -215,18 +215,6 @@ def run_rank(args) -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    elif not args.no_multistart and args.workload == "kinova":
-        # ONE rank: the RCCL leg of the multi-start record still runs (a one-rank group), so that the exchange step is executed code
-        # on every bench run, not only on the driver's multi-GPU node.  A group that cannot be created here is reported, not fatal.
-        try:
-            import torch.distributed as dist  # noqa: F811
-            from raptor_amd.launch import free_port
-
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
-                                    device_id=torch.device("cuda", local_rank))
-        except Exception as e:  # noqa: BLE001
-            rccl_note = f"one-rank RCCL group not created: {e}"
-            dist = None
 
     import raptor_amd
     from raptor_amd import _capi as A
@@ -581,6 +569,20 @@ def run_rank(args) -> None:
                                                           "single_problem_eval_jac_g_latency_ms", "single_problem_eval_jac_g_latency_ms_host",
                                                           "cpu_baseline") if k in sec}}
     if args.workload == "kinova" and not args.no_multistart:
+        if world == 1:
+            # ONE rank: the RCCL leg of the multi-start record still runs (a one-rank group), so that the exchange step is executed code
+            # on every bench run, not only on the driver's multi-GPU node.  A group that cannot be created here is reported, not fatal.
+            # Created HERE, after every other record: RCCL's helper threads, once alive, add ~30 us to the host-synchronised
+            # single-problem latency loops (Digit 167 -> 196 us when the group was created at the start of the run).
+            try:
+                import torch.distributed as dist  # noqa: F811
+                from raptor_amd.launch import free_port
+
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local_rank))
+            except Exception as e:  # noqa: BLE001
+                rccl_note = f"one-rank RCCL group not created: {e}"
+                dist = None
         ms = multistart_record()
         if out is not None:
             if ms is not None and rccl_note:
