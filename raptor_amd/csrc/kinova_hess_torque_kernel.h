@@ -14,7 +14,7 @@
 //     of joint b carried to the link being walked and Jd_b its rate (Jd_b = X_up Jd_b + (J_b x S_l) q_d_l, zero at link b) -- two
 //     more 6-vectors on lane b --
 //         V^ab = w0 V^a x J_b,   W^ab = w0 W^a x J_b,   A^ab = (w0 A^a + w1 V^a) x J_b + w0 V^a x Jd_b      (a <= b <= l),
-//     a = b included.  Moving the cross products onto the forces they are multiplied with, a pair's term at a link is five
+//     a = b included.  Moving the cross products onto the forces they are multiplied with, a pair's term at a link is six
 //     6-vector products of a covector of chain a with a vector of chain b:
 //         J_b.G^a + Jd_b.G2^a + f^b.W^a + W^b.f^a - U^a.H^b - U^b.H^a ,
 //         G^a  = -[w0 W^a x* f + (w0 A^a + w1 V^a) x* (I W) + w0 V^a x* c],   G2^a = -w0 V^a x* (I W),
