@@ -128,7 +128,8 @@ struct ChainGeo {
     V3 w[NJ], o[NJ], p;
 };
 template <int NJ, bool TOE, int CLOSURE, bool ROD>
-RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __restrict__ end, const double* th, ChainGeo<NJ>& g) {
+RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __restrict__ end, const double* th, ChainGeo<NJ>& g,
+                       M3* Rend = nullptr, V3* oend = nullptr) {
     M3 Rw;
 #pragma unroll
     for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -149,6 +150,7 @@ RD void chain_geometry(const DevChainJoint* __restrict__ J, const double* __rest
         ow = o;
     }
     g.p = ow + mul(Rw, v3(end[0], end[1], end[2]));
+    if (Rend != nullptr) { *Rend = Rw; *oend = ow; }
 }
 // D^2 p [u, v] and D^3 p [u, v, w] for per-joint direction components (chain order)
 template <int NJ>
@@ -199,10 +201,15 @@ struct LoopSolver {
     static constexpr bool TOE = NCL == 2;
     RD void geometry(const double* th) {
         chain_geometry<NA, TOE, 0, true>(L->cl[0].A, L->cl[0].endA, th, ga[0]);
-        chain_geometry<NB, TOE, 0, false>(L->cl[0].B, L->cl[0].endB, th, gb[0]);
+        M3 Rb;
+        V3 ob;
+        chain_geometry<NB, TOE, 0, false>(L->cl[0].B, L->cl[0].endB, th, gb[0], &Rb, &ob);
         if (NCL > 1) {
             chain_geometry<NA, TOE, 1, true>(L->cl[NCL - 1].A, L->cl[NCL - 1].endA, th, ga[NCL - 1]);
-            chain_geometry<NB, TOE, 1, false>(L->cl[NCL - 1].B, L->cl[NCL - 1].endB, th, gb[NCL - 1]);
+            // the toe loop's two closures hang on the SAME anchor chain (toe_pitch, toe_roll; checked at set-up): only the end point differs
+            gb[NCL - 1] = gb[0];
+            const double* e1 = L->cl[NCL - 1].endB;
+            gb[NCL - 1].p = ob + mul(Rb, v3(e1[0], e1[1], e1[2]));
         }
     }
     RD void residual(double* c) const {

@@ -1784,6 +1784,13 @@ int raptor_digit_problem_create(const raptor_model* model, const raptor_digit_de
                 if (type == 0) digit_knee_anchor(leg, an);
                 for (int k = 0; k < 3; k++) { cl.endA[k] = lp.rod[k]; cl.endB[k] = an[k]; }
             }
+            if (L.ncl == 2)  // digit_kernel.h evaluates the anchor chain once for both closures of the toe loop
+                for (int k = 0; k < 2; k++) {
+                    const DevChainJoint &a = L.cl[0].B[k], &b = L.cl[1].B[k];
+                    if (a.jtype != b.jtype || a.var != b.var || std::memcmp(a.plR, b.plR, sizeof(a.plR)) != 0 ||
+                        std::memcmp(a.plp, b.plp, sizeof(a.plp)) != 0)
+                        throw unsupported_error("Digit toe loop: the two closures do not share their anchor chain");
+                }
             for (int x = 0; x < ref.ndrv; x++) L.drv_traj[x] = ind_of[ids[ref.drv[x]]];
             // rows of the loop's closures in the compiled reference order: right toe-A, right toe-B, left toe-A, left toe-B,
             // right knee, left knee (DigitDynamicsConstraints.cpp:579-596)
