@@ -129,10 +129,17 @@ class Digit:
     batch = 4096
     bytes_per_se = None                   # 8 (rows / N) (n + 1) over the expand kernel's rows (torque, joint limits, contact, customized)
     flops_per_se = 1300000                # SURVEY.md 8d total for Digit as the reference does it
-    kernels = ["digit_loops_both_kernel (knee + toe) + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
-               "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
-               "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
-    pmc_keys = ["legged_core_kernel<32, true>", "legged_expand_kernel"]
+    # fused form (round 3): the core kernel writes every pg_pz row of the torque / joint-limit / contact / customized blocks itself
+    kernels = ["digit_loops_both_kernel (closed loops: knee + toe, Newton + implicit 1st-3rd derivatives)",
+               "legged_core_kernel<32,true,fused> (re-rooted RNEA, analytic derivatives, g rows, records, then the pg_pz rows of the "
+               "torque / joint-limit / contact / customized blocks in Optimizer order)",
+               "digit_period_loops_kernel + legged_period_kernel (reset-map rows)"]
+    rows_kernel = 1
+    pmc_keys = ["digit_loops_both_kernel", "legged_core_kernel<32, true, true>", "legged_period_kernel<36, 24, true>"]
+    kernels_unfused = ["digit_loops_both_kernel (knee + toe) + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
+                       "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
+                       "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
+    pmc_keys_unfused = ["legged_core_kernel<32, true>", "legged_expand_kernel"]
     bound = "hbm"
     z_scale = 0.1  # DigitSingleStep.cpp:75
     workload = ("Digit-v3 single-step gait, nv=36 (6 floating + 12 actuated + 18 closed-loop), Bezier degree 5, "
@@ -264,7 +271,7 @@ def run_rank(args) -> None:
             step()
         barrier()
         elapsed = time.perf_counter() - t0
-        n_prof, k0_ms, k1_ms = prob.profile_end()
+        n_prof, kms3 = prob.profile_end_split()
         per_rank_ms, ranks_seen = [1e3 * elapsed / args.steps], 1
         if dist is not None and world > 1:
             mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -279,9 +286,13 @@ def run_rank(args) -> None:
             return None
         sample_evals = B * W.samples
         assert args.no_check or (bool(torch.isfinite(G).all()) and bool(torch.isfinite(J).all()))
-        kms = [k0_ms, k1_ms]
-        dom = 0 if k0_ms >= k1_ms else 1   # the roofline is quoted on the longest kernel (group) of the evaluation
-        tot_s = (k0_ms + k1_ms) * 1e-3
+        # three timed intervals per evaluation (raptor_profile_end_split): kernels before the split | 0 | kernels after it, except on the
+        # fused legged path (loops | core kernel writing the rows | reset map)
+        if len(W.kernels) == 3 and kms3[1] < 0.02 * sum(kms3):  # RAPTOR_NO_FUSE=1 (A/B runs): the two-kernel form ran
+            W.kernels, W.pmc_keys, W.rows_kernel = W.kernels_unfused, W.pmc_keys_unfused, 1
+        kms = list(kms3) if len(W.kernels) == 3 else [kms3[0] + kms3[1], kms3[2]]
+        dom = max(range(len(kms)), key=lambda k: kms[k])   # the longest kernel (group) of the evaluation
+        tot_s = sum(kms) * 1e-3
         # legged workloads: the expand kernel writes every block but the reset map, which legged_period_kernel
         # writes once per z inside the first kernel group
         exp_rows = prob.m - (prob.block_offsets[-1] - prob.block_offsets[-2] if not W.name.startswith("kinova") else 0)
@@ -292,15 +303,16 @@ def run_rank(args) -> None:
         def hbm_line(k):
             """HBM roofline entry of timed kernel (group) k: the algorithmic output bytes belong to the kernel that writes them."""
             ms = kms[k]
-            writes_rows = (k == 0) if W.kernels[1] is None else (k == 1)
+            writes_rows = k == rows_k
             if not writes_rows or ms <= 0:
                 return {"kernel": W.kernels[k], "kernel_ms": ms, "achieved": None, "frac": None,
                         "note": "this kernel group leaves compact per-sample records, not the rows: its roof is fp64 issue, see roofline_fp64 / valu"}
             gbs = alg_bytes / (ms * 1e-3) / 1e9
             return {"kernel": W.kernels[k], "kernel_ms": ms, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
 
-        lines = [hbm_line(k) for k in (0, 1) if W.kernels[k]]
-        rows_k = 0 if W.kernels[1] is None else 1
+        rows_k = getattr(W, "rows_kernel", 0 if W.kernels[1] is None else 1)
+        lines_by_k = {k: hbm_line(k) for k in range(len(kms)) if W.kernels[k]}
+        lines = list(lines_by_k.values())
         traffic, pmc_note = pmc_traffic(W.pmc_keys[rows_k], W.name)
         out = {
             "metric": "RNEA+dtau/dz sample-evals/sec (fp64)",
@@ -328,10 +340,10 @@ def run_rank(args) -> None:
                 "kernel": W.kernels[rows_k],
                 "bound": "hbm",
                 "binding_roof": W.bound,
-                "achieved": lines[rows_k if len(lines) > 1 else 0]["achieved"],
+                "achieved": lines_by_k[rows_k]["achieved"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": lines[rows_k if len(lines) > 1 else 0]["frac"],
+                "frac": lines_by_k[rows_k]["frac"],
                 "traffic": traffic,
                 "traffic_source": pmc_note,
                 "kernel_ms": kms[rows_k],

@@ -391,6 +391,12 @@ int raptor_dual_kinova_arm_arm_batch_host(raptor_problem* problem1, raptor_probl
  */
 int raptor_profile_begin(raptor_problem* problem, int max_evaluations);
 int raptor_profile_end(raptor_problem* problem, int* evaluations, double* id_ms_avg, double* obs_ms_avg);
+/*
+ * Same, three intervals (ms_avg[3]): the events of an evaluation are start | split 1 | split 2 | end.  Legged problems whose
+ * core kernel also writes the pg_pz rows (the fused form, Digit): closed-loop kernel | core kernel | reset-map kernels.
+ * Every other path: kernels before the split | 0 | kernels after it (raptor_profile_end returns the first two added up).
+ */
+int raptor_profile_end_split(raptor_problem* problem, int* evaluations, double* ms_avg);
 
 /*
  * Costs::compute for the cost classes the single-step optimizers use (Costs/include/Costs.h:25-45):

@@ -232,7 +232,7 @@ EXPORTS = [
 STATUS_NOT_CONVERGED = 1
 STATUS_NONFINITE = 2
 # entry points that exist on the device library only (no oracle counterpart: nothing to compare)
-DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc", "shard_range", "violation_batch", "eval_batch_sharded"]
+DEVICE_ONLY_EXPORTS = ["probe_fill", "eval_h_batch_noalloc", "shard_range", "violation_batch", "eval_batch_sharded", "profile_end_split"]
 
 
 class CApi:
@@ -286,6 +286,7 @@ class CApi:
         f("profile_end").argtypes = [vp, _ip, _dp, _dp]
         if prefix == "raptor_":
             f("probe_fill").argtypes = [vp, C.c_longlong, C.c_longlong, vp]
+            f("profile_end_split").argtypes = [vp, _ip, _dp]
             f("eval_h_batch_noalloc").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
             f("shard_range").argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
             f("violation_batch").argtypes = [vp, vp, C.c_int, vp, vp]
@@ -637,6 +638,12 @@ class ProblemHandle:
         n, a, b = C.c_int(), C.c_double(), C.c_double()
         self.api.check(self.api.fn("profile_end")(self.handle, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
+
+    def profile_end_split(self):
+        """(evaluations, [ms, ms, ms]): start | split 1 | split 2 | end (fused legged path: loops | core | reset map)."""
+        n, ms = C.c_int(), (C.c_double * 3)()
+        self.api.check(self.api.fn("profile_end_split")(self.handle, C.byref(n), ms))
+        return n.value, [ms[0], ms[1], ms[2]]
 
     def trajectory_host(self, Z, N: int, Nact: int):
         Z = _f64(Z).reshape(-1, self.n)

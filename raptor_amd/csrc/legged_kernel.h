@@ -34,6 +34,9 @@
 #define LEG_EXP_BLOCK 256  // streaming kernel: threads per workgroup (one workgroup per sample-eval)
 #endif
 #define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
+#ifndef LEG_STAGGER
+#define LEG_STAGGER 4     // fused core kernel: start offset between the hardware slots of a CU, in s_sleep(127) units (measured 2 / 4 / 8 / 16)
+#endif
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -114,24 +117,142 @@ RD double contact_row(int r, const double* lam, const double* p, double mu, doub
     }
 }
 
+// Streams pg_pz out in Optimizer order.  One workgroup per sample-eval: the sample's record and the per-column Bernstein
+// weights are staged in LDS once; the three row blocks of this sample are contiguous pieces of the output
+// (rows i*R .. i*R + R - 1 of a block), written with one 16-byte store per lane and no integer division in the loop.
+//   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
+//   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
+// 16-byte store of two adjacent columns
+RD void store2_stream(double* p, double a, double b) {
+    v2d_t v = {a, b};
+#ifdef RAPTOR_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+#else
+    *reinterpret_cast<v2d_t*>(p) = v;  // plain stores measured faster than nontemporal ones at the 4 GB bench size
+#endif
+}
+
+template <int PIECE, int BLK = LEG_EXP_BLOCK>
+RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, const int cnt,
+                            double* __restrict__ dst, const double* __restrict__ rec0, const int recstride,
+                            const double* __restrict__ wB0, const int* __restrict__ tcol, const int* __restrict__ rowinfo,
+                            const DevLegged* __restrict__ Q) {
+    // `cnt` (1 or 2) consecutive samples of one decision vector: their rows of a block are adjacent, so the piece is one
+    // contiguous run of cnt * R rows
+    const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
+    const int dr = (2 * BLK) / n, dc = (2 * BLK) - dr * n;
+    const int total = cnt * R * n;
+    int el = 2 * tid;
+    int r = el / n, c = el - r * n;
+    for (; el < total; el += 2 * BLK) {
+        const int sidx = (r >= R) ? 1 : 0;
+        const int rr_ = r - sidx * R;
+        const double* rec = rec0 + sidx * recstride;
+        const double* wB = wB0 + sidx * 3 * ndyn;
+        double o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cc = c + h;
+            double val = 0.0;
+            if (cc < ndyn) {  // the v_reset / lambda_reset tail never enters (TalosSingleStepOptimizer.cpp:50-51)
+                const int t = tcol[cc];
+                const double B0 = wB[cc];
+                if (PIECE == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
+                    const double* d = rec + Q->c_D + (t * 3) * ni + rr_;
+                    val = d[0] * B0 + d[ni] * wB[ndyn + cc] + d[2 * ni] * wB[2 * ndyn + cc];
+                } else if (PIECE == 1) {  // ConstrainedJointLimits.cpp:59-68
+                    const double* Pb = rec + Q->c_P;
+                    const double* Pl = rec + Q->c_Pl;
+                    const int info = rowinfo[rr_];  // >= 0: independent index; < 0: -1 - dependent index
+                    if (info >= 0) {
+                        val = (info == t) ? B0 : 0.0;
+                    } else {
+                        const int dd = -1 - info;
+                        double g;
+                        if (dd < 6) g = Pb[dd * ni + t];
+                        else g = (t == rowinfo[RAPTOR_MAX_NV + 2 * dd]) ? Pl[(dd - 6) * 2] : ((t == rowinfo[RAPTOR_MAX_NV + 2 * dd + 1]) ? Pl[(dd - 6) * 2 + 1] : 0.0);
+                        val = g * B0;
+                    }
+                } else {  // RectangleSurfaceContactConstraints.cpp:52-93
+                    double p[6];
+                    const double B1 = wB[ndyn + cc], B2 = wB[2 * ndyn + cc];
+                    const double* l = rec + Q->c_L + t;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) p[q] = l[q * ni] * B0 + l[(6 + q) * ni] * B1 + l[(12 + q) * ni] * B2;
+                    val = contact_row(rr_, rec + Q->c_lam, p, mu, gam, Lx, Ly);
+                }
+            }
+            o[h] = val;
+        }
+        store2_stream(dst + el, o[0], o[1]);
+        r += dr;
+        c += dc;
+        if (c >= n) { c -= n; r++; }
+    }
+}
+
+// customized rows r0 .. r0 + nrows - 1: ONE contiguous run per workgroup (a workgroup that wrote the rows of its own samples
+// would scatter 1 KB rows over the block -- the block is ordered by quantity, then sample -- which costs 15 % of the write rate of
+// the whole kernel, scripts/bw_probe.py).  A row is (ca X[qa] + cb X[qb]) differentiated: coef[r][t] per actuator t (formed in the
+// prologue from the records of the row's sample) times the order-0 Bernstein weight of its sample.
+template <int BLK = LEG_EXP_BLOCK>
+RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int ni, const int K, const int nrows,
+                           double* __restrict__ dst, const double* __restrict__ coef, const int* __restrict__ rsample,
+                           const double* __restrict__ B0, const int* __restrict__ tcol) {
+    const int dr = (2 * BLK) / n, dc = (2 * BLK) - dr * n;
+    const int total = nrows * n;
+    int el = 2 * tid;
+    int r = el / n, c = el - r * n;
+    for (; el < total; el += 2 * BLK) {
+        const double* cf = coef + r * ni;
+        const double* w = B0 + rsample[r] * K;
+        double o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cc = c + h;
+            double val = 0.0;
+            if (cc < ndyn) {
+                const int t = tcol[cc];
+                val = cf[t] * w[cc - t * K];
+            }
+            o[h] = val;
+        }
+        store2_stream(dst + el, o[0], o[1]);
+        r += dr;
+        c += dc;
+        if (c >= n) { c -= n; r++; }
+    }
+}
+
 // Phase accounting: -DLEG_STOP=k ends the kernel after phase k with a checksum store.  Measurement builds only.
 #ifdef LEG_STOP
 #define LEG_PHASE_END(k, expr) if (LEG_STOP == (k)) { rec[g] = (expr); return; }
 #else
 #define LEG_PHASE_END(k, expr)
 #endif
-template <int LG, bool DERIV>
+template <int LG, bool DERIV, bool FUSE = false>
 __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
     const double* __restrict__ loops, const DevCustRow* __restrict__ cust, const int* __restrict__ cust_list,
-    const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec) {
+    const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec,
+    double* __restrict__ JAC = nullptr, const int stagger_wgs = 0) {
     // lamrec (may be null; the component view raptor_constrained_id_lambda_host only): per sample-eval the tree torque of every
     // closed-loop joint and its derivative per unit (q, v, a) of every actuator,  tau[nrec] | T[it][x][nrec]
     extern __shared__ __align__(16) double lds[];
     using LL = LegLds<LG>;
     constexpr int EPB = LEG_BLOCK / LG;
     const int tid = threadIdx.x;
+    if (FUSE && (int)blockIdx.x < stagger_wgs) {
+        // Fused form: every wavefront alternates a compute phase (bound by fp64 issue) with a store phase (bound by the write path).
+        // Launched together, the resident wavefronts of a CU run in lock step -- all compute, then all store -- and nothing overlaps
+        // (measured: no gain at all over two kernels).  The wavefronts of the FIRST round therefore start spread over a store phase by
+        // their hardware slot (SIMD, wave slot parity); later rounds inherit the offsets because every wavefront does the same work.
+        const unsigned simd = __builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4);  // HW_REG_HW_ID: wave_id [3:0], simd_id [5:4]
+        const unsigned wslot = __builtin_amdgcn_s_getreg((1 - 1) << 11 | 0 << 6 | 4);
+        const int slot = (int)(wslot * 4u + simd);
+        for (int k = 0; k < slot * LEG_STAGGER; k++) __builtin_amdgcn_s_sleep(127);  // 127 * 64 clocks ~ 3.5 us each
+    }
     const int g = tid & (LG - 1);
     const int eg = tid / LG;
     // a lane group past the end repeats the last sample-eval (same values to the same addresses): every lane of the wavefront
@@ -935,111 +1056,188 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // latency, and the second copy of the loop body costs more than it hides.)
 #pragma unroll 1
     for (int idx = 0; idx < nflat; idx++) f2_step(idx, f2_fetch(idx));
-}
 
-// Streams pg_pz out in Optimizer order.  One workgroup per sample-eval: the sample's record and the per-column Bernstein
-// weights are staged in LDS once; the three row blocks of this sample are contiguous pieces of the output
-// (rows i*R .. i*R + R - 1 of a block), written with one 16-byte store per lane and no integer division in the loop.
-//   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
-//   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
-// 16-byte store of two adjacent columns
-RD void store2_stream(double* p, double a, double b) {
-    v2d_t v = {a, b};
-#ifdef RAPTOR_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
-#else
-    *reinterpret_cast<v2d_t*>(p) = v;  // plain stores measured faster than nontemporal ones at the 4 GB bench size
-#endif
-}
-
-template <int PIECE>
-RD void legged_expand_piece(const int tid, const int n, const int ndyn, const int ni, const int R, const int cnt,
-                            double* __restrict__ dst, const double* __restrict__ rec0, const int recstride,
-                            const double* __restrict__ wB0, const int* __restrict__ tcol, const int* __restrict__ rowinfo,
-                            const DevLegged* __restrict__ Q) {
-    // `cnt` (1 or 2) consecutive samples of one decision vector: their rows of a block are adjacent, so the piece is one
-    // contiguous run of cnt * R rows
-    const double mu = Q->mu, gam = Q->gamma, Lx = Q->Lx, Ly = Q->Ly;
-    const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
-    const int total = cnt * R * n;
-    int el = 2 * tid;
-    int r = el / n, c = el - r * n;
-    for (; el < total; el += 2 * LEG_EXP_BLOCK) {
-        const int sidx = (r >= R) ? 1 : 0;
-        const int rr_ = r - sidx * R;
-        const double* rec = rec0 + sidx * recstride;
-        const double* wB = wB0 + sidx * 3 * ndyn;
-        double o[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int cc = c + h;
-            double val = 0.0;
-            if (cc < ndyn) {  // the v_reset / lambda_reset tail never enters (TalosSingleStepOptimizer.cpp:50-51)
-                const int t = tcol[cc];
-                const double B0 = wB[cc];
-                if (PIECE == 0) {  // TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
-                    const double* d = rec + Q->c_D + (t * 3) * ni + rr_;
-                    val = d[0] * B0 + d[ni] * wB[ndyn + cc] + d[2 * ni] * wB[2 * ndyn + cc];
-                } else if (PIECE == 1) {  // ConstrainedJointLimits.cpp:59-68
-                    const double* Pb = rec + Q->c_P;
-                    const double* Pl = rec + Q->c_Pl;
-                    const int info = rowinfo[rr_];  // >= 0: independent index; < 0: -1 - dependent index
-                    if (info >= 0) {
-                        val = (info == t) ? B0 : 0.0;
-                    } else {
-                        const int dd = -1 - info;
-                        double g;
-                        if (dd < 6) g = Pb[dd * ni + t];
-                        else g = (t == rowinfo[RAPTOR_MAX_NV + 2 * dd]) ? Pl[(dd - 6) * 2] : ((t == rowinfo[RAPTOR_MAX_NV + 2 * dd + 1]) ? Pl[(dd - 6) * 2 + 1] : 0.0);
-                        val = g * B0;
-                    }
-                } else {  // RectangleSurfaceContactConstraints.cpp:52-93
-                    double p[6];
-                    const double B1 = wB[ndyn + cc], B2 = wB[2 * ndyn + cc];
-                    const double* l = rec + Q->c_L + t;
-#pragma unroll
-                    for (int q = 0; q < 6; q++) p[q] = l[q * ni] * B0 + l[(6 + q) * ni] * B1 + l[(12 + q) * ni] * B2;
-                    val = contact_row(rr_, rec + Q->c_lam, p, mu, gam, Lx, Ly);
+    // ---- phase G (FUSE builds): the torque / joint-limit / contact rows of pg_pz of this wavefront's sample-evals, straight from its
+    // own records.  The expansion is bound by the write path and this kernel by fp64 issue: in one kernel the stores of one wavefront
+    // drain while the other wavefront of the SIMD computes, which two launches (or two streams: the core kernel holds all of a CU's LDS)
+    // never did.  With two wavefronts per SIMD nothing hides a chain of dependent LDS look-ups per element (the flat element loop of
+    // legged_expand_kernel run here took 0.97 ms on top of the core kernel's 0.66), so the mapping is lane = FIXED 16-byte column chunk:
+    // the lane's actuator and its six Bernstein weights per sample live in registers, a row costs 1-3 LDS reads at constant offsets,
+    // a few FMAs and one store.  Host conditions (legged_can_fuse): N even (a pair of sample-evals = consecutive samples of ONE decision
+    // vector), n and K even (a chunk's two columns belong to one actuator), ni * K <= 128 (chunks 64.. of a row are structural zeros),
+    // n <= 256, two records fit the wavefront's LDS area.  The customized block (ordered by quantity, then sample) stays with
+    // legged_expand_kernel, which then writes nothing else.
+    if constexpr (FUSE) {
+        const int stride = Q->c_stride, K = Q->K, n = L.n;
+        const int ndyn = ni * K, cpr = n >> 1;
+        const int ntail = cpr - LEG_BLOCK;  // chunks of a row beyond the wavefront's 64 (> 0 for Digit: 66 chunks)
+        const int cc = 2 * tid;
+        const bool live = cc < ndyn;
+        const bool lane_on = tid < cpr;
+        const int t = live ? cc / K : 0, kk = live ? cc - t * K : 0;
+        const int cD = Q->c_D, cP = Q->c_P, cPl = Q->c_Pl, cL = Q->c_L, clam = Q->c_lam;
+        const int off_tau = Q->off_tau, off_q = Q->off_q, off_contact = Q->off_contact;
+        const v2d_t zero2 = v2d_t{0.0, 0.0};
+        double* xrec = lds;  // [2][stride]
+        // lane j < nv: what row j of the joint-limit block is (independent column, floating-base row, closed-loop row and its two
+        // driver columns) -- fetched by the lanes in parallel and handed out with v_readlane: three dependent scalar loads per row were
+        // most of this phase's time
+        int ri_info = 0, ri_c0 = -1, ri_c1 = -1;
+        if (tid < nv) {
+            const int ind = Q->joint_ind[tid];
+            const int dd = Q->joint_dep[tid];
+            ri_info = ind >= 0 ? ind : -1 - dd;
+            if (ind < 0 && dd >= 6) { ri_c0 = Q->dep_col[dd][0]; ri_c1 = Q->dep_col[dd][1]; }
+        }
+        const int ncust = Q->ncust, off_cust = Q->off_cust, cPsf = Q->c_Psf;
+#pragma unroll 1
+        for (int rd = 0; rd < EPB / 2; rd++) {
+            const long long ea = e0 + 2 * rd;
+            if (ea >= E) break;  // (uniform)
+            int ia = (int)(e0 - b0 * N) + 2 * rd;
+            long long ba = b0;
+            while (ia >= N) { ia -= N; ba++; }
+            wave_sync();  // the record stores above and the loads below are one wavefront's vector-memory operations: performed in order
+            const double* src = core + (size_t)ea * stride;
+            for (int k = tid; k < 2 * stride; k += LEG_BLOCK) xrec[k] = src[k];
+            // customized rows of these two samples: lane g of group sx holds the g-th row of sample ia + sx (host: <= LG rows per sample)
+            int cu_row = 0, cu_qa = 0, cu_qb = -1, cu_n = 0;
+            double cu_ca = 0.0, cu_cb = 0.0;
+            if (ncust > 0) {
+                const int cs = cust_start[ia + eg];
+                cu_n = cust_start[ia + eg + 1] - cs;
+                if (g < cu_n) {
+                    cu_row = cust_list[cs + g];
+                    const DevCustRow cr = cust[cu_row];
+                    cu_qa = cr.qa; cu_qb = cr.qb; cu_ca = cr.ca; cu_cb = cr.cb;
                 }
             }
-            o[h] = val;
-        }
-        store2_stream(dst + el, o[0], o[1]);
-        r += dr;
-        c += dc;
-        if (c >= n) { c -= n; r++; }
-    }
-}
-
-// customized rows r0 .. r0 + nrows - 1: ONE contiguous run per workgroup (a workgroup that wrote the rows of its own samples
-// would scatter 1 KB rows over the block -- the block is ordered by quantity, then sample -- which costs 15 % of the write rate of
-// the whole kernel, scripts/bw_probe.py).  A row is (ca X[qa] + cb X[qb]) differentiated: coef[r][t] per actuator t (formed in the
-// prologue from the records of the row's sample) times the order-0 Bernstein weight of its sample.
-RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int ni, const int K, const int nrows,
-                           double* __restrict__ dst, const double* __restrict__ coef, const int* __restrict__ rsample,
-                           const double* __restrict__ B0, const int* __restrict__ tcol) {
-    const int dr = (2 * LEG_EXP_BLOCK) / n, dc = (2 * LEG_EXP_BLOCK) - dr * n;
-    const int total = nrows * n;
-    int el = 2 * tid;
-    int r = el / n, c = el - r * n;
-    for (; el < total; el += 2 * LEG_EXP_BLOCK) {
-        const double* cf = coef + r * ni;
-        const double* w = B0 + rsample[r] * K;
-        double o[2];
+            double W[2][3][2];  // [sample][order][column of the chunk]
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int cc = c + h;
-            double val = 0.0;
-            if (cc < ndyn) {
-                const int t = tcol[cc];
-                val = cf[t] * w[cc - t * K];
+            for (int sx = 0; sx < 2; sx++)
+#pragma unroll
+                for (int o = 0; o < 3; o++) {
+                    const double* Bs = basis + (size_t)((ia + sx) * 3 + o) * K + kk;
+                    W[sx][o][0] = live ? Bs[0] : 0.0;
+                    W[sx][o][1] = live ? Bs[1] : 0.0;
+                }
+            wave_sync();
+            double* base = JAC + (size_t)ba * L.m * n + cc;
+            // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
+            {
+                double* dst = base + ((size_t)off_tau + (size_t)ia * ni) * n;
+#pragma unroll
+                for (int sx = 0; sx < 2; sx++) {
+                    const double* d = xrec + sx * stride + cD + (t * 3) * ni;
+                    const double B00 = W[sx][0][0], B01 = W[sx][0][1], B10 = W[sx][1][0], B11 = W[sx][1][1], B20 = W[sx][2][0], B21 = W[sx][2][1];
+#pragma unroll 4
+                    for (int rr = 0; rr < ni; rr++) {
+                        const double d0 = d[rr], d1 = d[ni + rr], d2 = d[2 * ni + rr];
+                        const double v0 = d0 * B00 + d1 * B10 + d2 * B20;
+                        const double v1 = d0 * B01 + d1 * B11 + d2 * B21;
+                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + rr) * n) = v2d_t{v0, v1};
+                    }
+                }
+                for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * ni; r += LEG_BLOCK / ntail)
+                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
-            o[h] = val;
+            // -- ConstrainedJointLimits.cpp:59-68
+            {
+                double* dst = base + ((size_t)off_q + (size_t)ia * nv) * n;
+#pragma unroll 1
+                for (int j = 0; j < nv; j++) {
+                    const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
+                    if (info >= 0) {
+                        const bool me = live && info == t;
+#pragma unroll
+                        for (int sx = 0; sx < 2; sx++)
+                            if (lane_on)
+                                *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * nv + j) * n) = v2d_t{me ? W[sx][0][0] : 0.0, me ? W[sx][0][1] : 0.0};
+                    } else {
+                        const int dd = -1 - info;
+                        double gq[2];
+                        if (dd < 6) {
+#pragma unroll
+                            for (int sx = 0; sx < 2; sx++) gq[sx] = xrec[sx * stride + cP + dd * ni + t];
+                        } else {
+                            const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
+#pragma unroll
+                            for (int sx = 0; sx < 2; sx++) {
+                                const double* Pl = xrec + sx * stride + cPl + (dd - 6) * 2;
+                                const double p0 = Pl[0], p1 = Pl[1];
+                                gq[sx] = (t == c0) ? p0 : ((t == c1) ? p1 : 0.0);
+                            }
+                        }
+#pragma unroll
+                        for (int sx = 0; sx < 2; sx++)
+                            if (lane_on)
+                                *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * nv + j) * n) = v2d_t{gq[sx] * W[sx][0][0], gq[sx] * W[sx][0][1]};
+                    }
+                }
+                for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * nv; r += LEG_BLOCK / ntail)
+                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
+            }
+            // -- RectangleSurfaceContactConstraints.cpp:52-93
+            {
+                double* dst = base + ((size_t)off_contact + (size_t)ia * 7) * n;
+#pragma unroll
+                for (int sx = 0; sx < 2; sx++) {
+                    const double* l = xrec + sx * stride + cL + t;
+                    double p[2][6];
+#pragma unroll
+                    for (int q6 = 0; q6 < 6; q6++) {
+                        const double l0 = l[q6 * ni], l1 = l[(6 + q6) * ni], l2 = l[(12 + q6) * ni];
+                        p[0][q6] = l0 * W[sx][0][0] + l1 * W[sx][1][0] + l2 * W[sx][2][0];
+                        p[1][q6] = l0 * W[sx][0][1] + l1 * W[sx][1][1] + l2 * W[sx][2][1];
+                    }
+                    const double* lam = xrec + sx * stride + clam;
+#pragma unroll
+                    for (int rr = 0; rr < 7; rr++) {
+                        const double v0 = live ? contact_row(rr, lam, p[0], mu, gam, Lx, Ly) : 0.0;
+                        const double v1 = live ? contact_row(rr, lam, p[1], mu, gam, Lx, Ly) : 0.0;
+                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1};
+                    }
+                }
+                for (int r = tid / max(ntail, 1); ntail > 0 && r < 14; r += LEG_BLOCK / ntail)
+                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
+            }
+            // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base]
+            if (ncust > 0) {
+                double* dst = base + (size_t)off_cust * n;
+#pragma unroll
+                for (int sx = 0; sx < 2; sx++) {
+                    const int cnt = __builtin_amdgcn_readlane(cu_n, sx * LG);
+                    const double* rs = xrec + sx * stride;
+#pragma unroll 1
+                    for (int r = 0; r < cnt; r++) {
+                        const int sl_ = sx * LG + r;
+                        const int row = __builtin_amdgcn_readlane(cu_row, sl_);
+                        const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
+                        const long long cai = __double_as_longlong(cu_ca), cbi = __double_as_longlong(cu_cb);
+                        const double ca = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(cai >> 32), sl_) << 32) | (unsigned)__builtin_amdgcn_readlane((int)cai, sl_));
+                        const double cb = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(cbi >> 32), sl_) << 32) | (unsigned)__builtin_amdgcn_readlane((int)cbi, sl_));
+                        const double da = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
+                        const double db = (qb < 0) ? 0.0 : rs[((qb < 6) ? cPsf + qb * ni : cP + (qb - 6) * ni) + t];
+                        const double cf = ca * da + cb * db;
+                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)row * n) = v2d_t{live ? cf * W[sx][0][0] : 0.0, live ? cf * W[sx][0][1] : 0.0};
+                    }
+                }
+                if (ntail > 0) {  // chunks 64.. of those rows: lane -> (sample, row of the sample, chunk)
+                    const int per = LEG_BLOCK / ntail;  // rows per store
+                    const int n0 = __builtin_amdgcn_readlane(cu_n, 0), n1 = __builtin_amdgcn_readlane(cu_n, LG);
+                    for (int rb = 0; rb < n0 + n1; rb += per) {  // (uniform trip count: the shuffle below needs every lane)
+                        const int r = rb + tid / ntail;
+                        const bool on = r < n0 + n1 && tid < per * ntail;
+                        const int sl_ = on ? ((r < n0) ? r : LG + (r - n0)) : 0;
+                        const int row = __shfl(cu_row, sl_);
+                        if (on) *reinterpret_cast<v2d_t*>(dst - cc + (size_t)row * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
+                    }
+                }
+            }
         }
-        store2_stream(dst + el, o[0], o[1]);
-        r += dr;
-        c += dc;
-        if (c >= n) { c -= n; r++; }
     }
 }
 
@@ -1048,7 +1246,8 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
                                                                      const double* __restrict__ basis, const DevLayout L,
                                                                      const double* __restrict__ core,
                                                                      const DevCustRow* __restrict__ cust, const int spw,
-                                                                     const int cper, double* __restrict__ JAC) {
+                                                                     const int cper, const int pieces, double* __restrict__ JAC) {
+    // pieces == 0: the customized block only (the other three came out of the fused core kernel)
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int N = T->N;
@@ -1070,8 +1269,9 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
     const int r0 = (int)(blockIdx.x - b * groups) * cper;         // this workgroup's run of customized rows
     const int crows = max(0, min(cper, Q->ncust - r0));
     const double* src = core + (size_t)e * stride;                // the records of consecutive samples are adjacent
-    for (int k = tid; k < cnt * stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
-    for (int c = tid; c < cnt * ndyn; c += LEG_EXP_BLOCK) {
+    if (pieces)
+        for (int k = tid; k < cnt * stride; k += LEG_EXP_BLOCK) rec[k] = src[k];
+    for (int c = tid; c < (pieces ? cnt : 1) * ndyn; c += LEG_EXP_BLOCK) {
         const int sidx = (c >= ndyn) ? 1 : 0;
         const int cc = c - sidx * ndyn;
         const int t = cc / K, k = cc - t * K;
@@ -1103,9 +1303,11 @@ __global__ __launch_bounds__(LEG_EXP_BLOCK) void legged_expand_kernel(const DevT
     __syncthreads();
     // the row blocks of these samples are contiguous pieces of the output; 16-byte aligned because n is even
     double* base = JAC + (size_t)b * L.m * n;
+    if (pieces) {
     legged_expand_piece<0>(tid, n, ndyn, ni, ni, cnt, base + ((size_t)Q->off_tau + (size_t)i * ni) * n, rec, stride, wB, tcol, rowinfo, Q);
     legged_expand_piece<1>(tid, n, ndyn, ni, nv, cnt, base + ((size_t)Q->off_q + (size_t)i * nv) * n, rec, stride, wB, tcol, rowinfo, Q);
     legged_expand_piece<2>(tid, n, ndyn, ni, 7, cnt, base + ((size_t)Q->off_contact + (size_t)i * 7) * n, rec, stride, wB, tcol, rowinfo, Q);
+    }
     if (crows > 0)
         legged_expand_cust(tid, n, ndyn, ni, K, crows, base + ((size_t)Q->off_cust + r0) * n, coef, rsample, B0, tcol);
 }

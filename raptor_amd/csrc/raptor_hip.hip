@@ -195,6 +195,7 @@ struct raptor_problem {
     DevBuf<int> d_kinds;
     DevBuf<DevCustRow> d_cust;       // customized block: row specs by row, per-sample row lists
     DevBuf<int> d_cust_list, d_cust_start;
+    int cust_max_per_sample = 0;  // most customized rows any one sample has (the fused core kernel holds a sample's rows in its lane group)
     bool has_period = false;         // reset-map tables present (period_kernel.h)
     bool period_rows = false;        // ... and the block is part of this problem's rows
     DevPeriod hper;
@@ -684,8 +685,32 @@ void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, 
 }
 
 // core kernel (values + compact derivative records), then the streaming expansion into pg_pz
+// fused form (round 3): the wide core kernel also writes the torque / joint-limit / contact rows of pg_pz (phase G) -- only the
+// customized block is left for legged_expand_kernel
+bool legged_can_fuse(const raptor_problem& p, const double* dJ) {
+    static const bool no_fuse = std::getenv("RAPTOR_NO_FUSE") != nullptr;
+    const int ndyn = p.hleg.ni * p.hleg.K;
+    if (no_fuse || p.hleg.nb <= 16 || p.htraj.N % 2 != 0 || p.layout.n % 2 != 0 || p.hleg.K % 2 != 0 || ((size_t)dJ & 15) != 0) return false;
+    if (ndyn > 2 * LEG_BLOCK || p.layout.n > 4 * LEG_BLOCK || p.layout.n < ndyn || p.cust_max_per_sample > 32) return false;
+    return (size_t)2 * p.hleg.c_stride <= (size_t)2 * LegLds<32>::STRIDE;
+}
+
+// wavefronts of the fused core kernel resident at once on the current device (8 one-wavefront workgroups per CU: LDS and registers)
+int fused_first_round() {
+    static int per_dev[64] = {0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return 2048;
+    if (per_dev[dev] == 0) {
+        int cus = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        per_dev[dev] = 8 * std::max(cus, 1);
+    }
+    return per_dev[dev];
+}
+
 void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, bool deriv, hipStream_t st, double* d_lamrec = nullptr,
-                        hipEvent_t after_loops = nullptr) {
+                        hipEvent_t after_loops = nullptr, double* dJ_fused = nullptr) {
     const long long E = (long long)B * p.htraj.N;
     if (E == 0) return;
     p.s_core.ensure((size_t)E * p.hleg.c_stride);
@@ -709,7 +734,11 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
                        p.d_cust_start.p, dG, p.s_core.p, d_lamrec)
-    if (wide) {
+    if (wide && deriv && dJ_fused != nullptr) {
+        hipLaunchKernelGGL((legged_core_kernel<32, true, true>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p, p.d_traj.p,
+                           p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, dG,
+                           p.s_core.p, d_lamrec, dJ_fused, fused_first_round());
+    } else if (wide) {
         if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
     } else {
         if (deriv) LEG_LAUNCH(16, true); else LEG_LAUNCH(16, false);
@@ -751,7 +780,7 @@ void launch_period(raptor_problem& p, const double* dZ, int B, double* dG, doubl
 }
 
 void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, double* dJ, bool jac, hipStream_t st,
-                   hipEvent_t between) {
+                   hipEvent_t between, hipEvent_t split1 = nullptr) {
     const long long E = (long long)B * p.htraj.N;
     // Small batches (one Ipopt-driven problem): the launches are a chain of latencies on a nearly empty GPU, so the reset-map kernels
     // go to a side stream -- their loop part beside the core kernel, the block itself beside the expansion (disjoint rows out, the
@@ -762,6 +791,8 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     // kernels to run beside the core kernel and lose ~10 us at every size (one G1 problem: 87.6 us forked, 77.5 us on one stream).
     static const long long fork_max = std::getenv("RAPTOR_FORK_MAX") ? std::atoll(std::getenv("RAPTOR_FORK_MAX")) : 16384;
     static const bool fork_forced = std::getenv("RAPTOR_FORK_MAX") != nullptr;  // experiments: also under per-kernel timing
+    const bool fused = jac && B > 0 && legged_can_fuse(p, dJ);
+    double* const dJf = fused ? dJ : nullptr;
     const bool fork = !no_fork && (p.has_digit || fork_forced) && p.period_rows && jac && B > 0 && E <= fork_max && (between == nullptr || fork_forced);
     if (fork) {
         if (p.side == nullptr) {
@@ -770,18 +801,26 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
             HIP_CHECK(hipEventCreateWithFlags(&p.ev_core, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&p.ev_side, hipEventDisableTiming));
         }
-        launch_legged_core(p, dZ, B, dG, jac, st, nullptr, p.ev_loops);
+        launch_legged_core(p, dZ, B, dG, jac, st, nullptr, p.ev_loops, dJf);
         HIP_CHECK(hipEventRecord(p.ev_core, st));
         HIP_CHECK(hipStreamWaitEvent(p.side, p.ev_loops, 0));
         launch_period(p, dZ, B, dG, dJ, jac, p.side, p.layout.m, p.hper.off, nullptr, nullptr, nullptr, p.ev_core);
         HIP_CHECK(hipEventRecord(p.ev_side, p.side));
     } else {
-        launch_legged_core(p, dZ, B, dG, jac, st);
+        // per-kernel timing: the fused form splits loops | core (every row but the reset map's) | reset map, the two-kernel form
+        // records | (nothing) | expansion
+        launch_legged_core(p, dZ, B, dG, jac, st, nullptr, fused ? split1 : nullptr, dJf);
+        if (fused && between) HIP_CHECK(hipEventRecord(between, st));
         if (p.period_rows && B > 0) launch_period(p, dZ, B, dG, dJ, jac, st, p.layout.m, p.hper.off, nullptr, nullptr, nullptr);
     }
-    if (between) HIP_CHECK(hipEventRecord(between, st));
+    if (!(fused && !fork)) {
+        if (split1) HIP_CHECK(hipEventRecord(split1, st));
+        if (between) HIP_CHECK(hipEventRecord(between, st));
+    }
     if (!jac || B == 0) return;
-    if (p.layout.n % 2 == 0 && ((size_t)dJ & 15) == 0) {
+    if (fused) {
+        // every row came out of the core kernel (phase G)
+    } else if (p.layout.n % 2 == 0 && ((size_t)dJ & 15) == 0) {
         if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
         const int ndyn = p.hleg.ni * p.hleg.K;
         const int spw = p.htraj.N >= 2 ? 2 : 1;  // two consecutive samples per workgroup: longer contiguous pieces, half the prologues
@@ -790,7 +829,7 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
         const size_t lds_bytes = (size_t)(spw * (p.hleg.c_stride + 3 * ndyn) + cper * p.hleg.ni + p.htraj.N * p.hleg.K) * sizeof(double) +
                                  (size_t)(ndyn + 3 * RAPTOR_MAX_NV + cper + 1) * sizeof(int);
         hipLaunchKernelGGL(legged_expand_kernel, dim3((unsigned)((long long)B * groups)), dim3(LEG_EXP_BLOCK), lds_bytes, st, p.d_traj.p,
-                           p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, spw, cper, dJ);
+                           p.d_leg.p, p.d_basis.p, p.layout, p.s_core.p, p.d_cust.p, spw, cper, 1, dJ);
     } else {
         const long long total = (long long)B * p.layout.m * p.layout.n;
         if (total / RAPTOR_BLOCK > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
@@ -810,7 +849,8 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
     check_launchable(p, B);
     if (B == 0) return;
     if (!(flags & RAPTOR_EVAL_G)) dG = nullptr;
-    const bool prof = p.profiling && p.ev_used + 3 <= p.ev.size();
+    // events per evaluation: start | first split | second split | end (the two splits coincide except on the fused legged path)
+    const bool prof = p.profiling && p.ev_used + 4 <= p.ev.size();
     if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used], st));
     if (p.kind == 1) {  // Kinova: one fused kernel
         if (jac) launch_kinova<true>(p, dZ, B, dG, dJ, st);
@@ -829,7 +869,10 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
             if (E > 0x7fffffffLL) throw std::invalid_argument("batch too large for one launch");
             p.s_core.ensure((size_t)E * KREC_STRIDE);
             launch_kinova<true, true>(p, dZ, B, dG, p.s_core.p, st);
-            if (prof) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+            if (prof) {
+                HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
+                HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
+            }
             int spb = 4;  // samples per workgroup: longer contiguous pieces per store stream
             if (const char* ev = getenv("RAPTOR_LH_SPB")) spb = std::max(1, std::min(8, atoi(ev)));
             const size_t per_sample = (size_t)(KREC_STRIDE + 3 * p.layout.n) * sizeof(double);
@@ -841,15 +884,18 @@ void eval_device(raptor_problem& p, const double* dZ, int B, unsigned flags, dou
             HIP_CHECK(hipGetLastError());
         }
     } else if (p.kind == 2) {  // legged: core kernel, then the streaming expansion (timed separately)
-        launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st, prof ? p.ev[p.ev_used + 1] : nullptr);
+        launch_legged(p, dZ, B, dG, jac ? dJ : nullptr, jac, st, prof ? p.ev[p.ev_used + 2] : nullptr, prof ? p.ev[p.ev_used + 1] : nullptr);
     } else {
         if (jac) launch_id<true>(p, p.layout, dZ, B, dG, dJ, st);
         else launch_id<false>(p, p.layout, dZ, B, dG, nullptr, st);
     }
-    if (prof && p.kind != 2 && !(p.kind == 3 && jac)) HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
-    if (prof) {
+    if (prof && p.kind != 2 && !(p.kind == 3 && jac)) {
+        HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 1], st));
         HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 2], st));
-        p.ev_used += 3;
+    }
+    if (prof) {
+        HIP_CHECK(hipEventRecord(p.ev[p.ev_used + 3], st));
+        p.ev_used += 4;
     }
 }
 
@@ -1594,6 +1640,8 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
         for (int i = 0; i < N; i++) start[i + 1] += start[i];
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int r = 0; r < Q.ncust; r++) list[fill[crow[r].sample]++] = r;
+        p->cust_max_per_sample = 0;
+        for (int i = 0; i < N; i++) p->cust_max_per_sample = std::max(p->cust_max_per_sample, start[i + 1] - start[i]);
         if (crow.empty()) crow.push_back(DevCustRow{0, 0, -1, 0, 0, 0, 0});
         p->d_cust.upload(crow.data(), crow.size());
         p->d_cust_list.upload(list.data(), list.size());
@@ -2459,7 +2507,7 @@ int raptor_eval_h_batch_host(raptor_problem* p, const double* Z, int B, const do
 int raptor_profile_begin(raptor_problem* p, int max_evaluations) {
     API_TRY
     if (!p || max_evaluations < 0) throw std::invalid_argument("bad argument");
-    while (p->ev.size() < (size_t)max_evaluations * 3) {
+    while (p->ev.size() < (size_t)max_evaluations * 4) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreate(&e));
         p->ev.push_back(e);
@@ -2469,25 +2517,33 @@ int raptor_profile_begin(raptor_problem* p, int max_evaluations) {
     API_CATCH
 }
 
-int raptor_profile_end(raptor_problem* p, int* evaluations, double* id_ms_avg, double* obs_ms_avg) {
+int raptor_profile_end_split(raptor_problem* p, int* evaluations, double* ms_avg) {
     API_TRY
     if (!p) throw std::invalid_argument("null problem");
     p->profiling = false;
-    const size_t n = p->ev_used / 3;
-    double a = 0, b = 0;
+    const size_t n = p->ev_used / 4;
+    double acc[3] = {0, 0, 0};
     for (size_t i = 0; i < n; i++) {
-        HIP_CHECK(hipEventSynchronize(p->ev[3 * i + 2]));
-        float t0 = 0, t1 = 0;
-        HIP_CHECK(hipEventElapsedTime(&t0, p->ev[3 * i], p->ev[3 * i + 1]));
-        HIP_CHECK(hipEventElapsedTime(&t1, p->ev[3 * i + 1], p->ev[3 * i + 2]));
-        a += t0;
-        b += t1;
+        HIP_CHECK(hipEventSynchronize(p->ev[4 * i + 3]));
+        for (int k = 0; k < 3; k++) {
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, p->ev[4 * i + k], p->ev[4 * i + k + 1]));
+            acc[k] += t;
+        }
     }
     if (evaluations) *evaluations = (int)n;
-    if (id_ms_avg) *id_ms_avg = n ? a / n : 0.0;
-    if (obs_ms_avg) *obs_ms_avg = n ? b / n : 0.0;
+    if (ms_avg)
+        for (int k = 0; k < 3; k++) ms_avg[k] = n ? acc[k] / n : 0.0;
     p->ev_used = 0;
     API_CATCH
+}
+
+int raptor_profile_end(raptor_problem* p, int* evaluations, double* id_ms_avg, double* obs_ms_avg) {
+    double ms[3] = {0, 0, 0};
+    const int rc = raptor_profile_end_split(p, evaluations, ms);
+    if (id_ms_avg) *id_ms_avg = ms[0] + ms[1];
+    if (obs_ms_avg) *obs_ms_avg = ms[2];
+    return rc;
 }
 
 int raptor_capsule_distance_batch(const double* d_P, const double* d_dP, const double* d_R, int n_pairs, int F,
