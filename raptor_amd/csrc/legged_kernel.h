@@ -37,6 +37,18 @@
 #ifndef LEG_STAGGER
 #define LEG_STAGGER 4     // fused core kernel: start offset between the hardware slots of a CU, in s_sleep(127) units (measured 2 / 4 / 8 / 16)
 #endif
+// fused core kernel, phase G: at most this many of a wavefront's stores in flight (s_waitcnt vmcnt): the CU's vector-memory path is
+// in order, so the loads of the wavefronts that compute wait behind whatever the storing wavefronts have queued
+#ifdef LEG_G_VMCNT
+#define LEG_G_THROTTLE __builtin_amdgcn_s_waitcnt(((LEG_G_VMCNT) & 15) | (7 << 4) | (15 << 8) | (((LEG_G_VMCNT) >> 4) << 14));
+#else
+#define LEG_G_THROTTLE
+#endif
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 1  // measurement build: phase G without its stores (one lane in 2^20 keeps the values alive)
+#define LEG_G_ON(c) ((c) && (tid + (int)blockIdx.x * 64) % 1048576 == 12345)
+#else
+#define LEG_G_ON(c) (c)
+#endif
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -1098,8 +1110,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             long long ba = b0;
             while (ia >= N) { ia -= N; ba++; }
             wave_sync();  // the record stores above and the loads below are one wavefront's vector-memory operations: performed in order
-            const double* src = core + (size_t)ea * stride;
-            for (int k = tid; k < 2 * stride; k += LEG_BLOCK) xrec[k] = src[k];
             // customized rows of these two samples: lane g of group sx holds the g-th row of sample ia + sx (host: <= LG rows per sample)
             int cu_row = 0, cu_qa = 0, cu_qb = -1, cu_n = 0;
             double cu_ca = 0.0, cu_cb = 0.0;
@@ -1121,8 +1131,29 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     W[sx][o][0] = live ? Bs[0] : 0.0;
                     W[sx][o][1] = live ? Bs[1] : 0.0;
                 }
+            {   // the two records back from L2, 16 bytes per lane and seven loads in flight (one load per trip of a plain loop is a chain of
+                // ~28 L2 round trips: 0.16 ms of the launch)
+                const v2d_t* src2 = reinterpret_cast<const v2d_t*>(core + (size_t)ea * stride);
+                v2d_t* dst2 = reinterpret_cast<v2d_t*>(xrec);
+                const int nch = stride;  // 2 * stride doubles
+#pragma unroll 1
+                for (int k0 = 0; k0 < nch; k0 += 7 * LEG_BLOCK) {
+                    v2d_t buf[7];
+#pragma unroll
+                    for (int u = 0; u < 7; u++) buf[u] = src2[min(k0 + u * LEG_BLOCK + tid, nch - 1)];
+#pragma unroll
+                    for (int u = 0; u < 7; u++)
+                        if (k0 + u * LEG_BLOCK + tid < nch) dst2[k0 + u * LEG_BLOCK + tid] = buf[u];
+                }
+            }
             wave_sync();
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 2  // measurement build: the readback alone
+            if (tid == 0) JAC[(size_t)ea] = xrec[tid] + xrec[stride + 5] + W[0][0][0] + W[1][2][1];
+            continue;
+#endif
             double* base = JAC + (size_t)ba * L.m * n + cc;
+            // Every piece below works in blocks of rows: all LDS reads of a block are issued before the first of them is used (with two
+            // wavefronts per SIMD nothing else hides an LDS round trip per row), rows past the end repeat the last row's reads and store nothing.
             // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
             {
                 double* dst = base + ((size_t)off_tau + (size_t)ia * ni) * n;
@@ -1130,99 +1161,125 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 for (int sx = 0; sx < 2; sx++) {
                     const double* d = xrec + sx * stride + cD + (t * 3) * ni;
                     const double B00 = W[sx][0][0], B01 = W[sx][0][1], B10 = W[sx][1][0], B11 = W[sx][1][1], B20 = W[sx][2][0], B21 = W[sx][2][1];
-#pragma unroll 4
-                    for (int rr = 0; rr < ni; rr++) {
-                        const double d0 = d[rr], d1 = d[ni + rr], d2 = d[2 * ni + rr];
-                        const double v0 = d0 * B00 + d1 * B10 + d2 * B20;
-                        const double v1 = d0 * B01 + d1 * B11 + d2 * B21;
-                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + rr) * n) = v2d_t{v0, v1};
+#pragma unroll 1
+                    for (int r0 = 0; r0 < ni; r0 += 6) {
+                        double d0[6], d1[6], d2[6];
+#pragma unroll
+                        for (int u = 0; u < 6; u++) {
+                            const int rr = min(r0 + u, ni - 1);
+                            d0[u] = d[rr]; d1[u] = d[ni + rr]; d2[u] = d[2 * ni + rr];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 6; u++) {
+                            const double v0 = d0[u] * B00 + d1[u] * B10 + d2[u] * B20;
+                            const double v1 = d0[u] * B01 + d1[u] * B11 + d2[u] * B21;
+                            if (LEG_G_ON(lane_on && r0 + u < ni)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + r0 + u) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
+                        }
                     }
                 }
                 for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * ni; r += LEG_BLOCK / ntail)
-                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
                         *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
-            // -- ConstrainedJointLimits.cpp:59-68
+            // -- ConstrainedJointLimits.cpp:59-68: row j is B_k at the joint's own column (independent joint) or P_dep(j, t) B_k
             {
                 double* dst = base + ((size_t)off_q + (size_t)ia * nv) * n;
 #pragma unroll 1
-                for (int j = 0; j < nv; j++) {
-                    const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
-                    if (info >= 0) {
-                        const bool me = live && info == t;
+                for (int j0 = 0; j0 < nv; j0 += 6) {
+                    double g0[6], g1[6], one[6];
+                    bool isind[6], take[6];
 #pragma unroll
-                        for (int sx = 0; sx < 2; sx++)
-                            if (lane_on)
-                                *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * nv + j) * n) = v2d_t{me ? W[sx][0][0] : 0.0, me ? W[sx][0][1] : 0.0};
-                    } else {
+                    for (int u = 0; u < 6; u++) {
+                        const int j = min(j0 + u, nv - 1);
+                        const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
+                        const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
                         const int dd = -1 - info;
-                        double gq[2];
-                        if (dd < 6) {
+                        isind[u] = info >= 0;
+                        const bool isbase = dd < 6;
+                        // one unconditional read per sample from an address every lane may read: an independent row reads entry 0 and drops it
+                        const int offu = isind[u] ? 0 : (isbase ? cP + dd * ni : cPl + (dd - 6) * 2);
+                        const int offl = isind[u] ? 0 : (isbase ? t : ((t == c0) ? 0 : 1));
+                        take[u] = isbase || t == c0 || t == c1;
+                        one[u] = (live && info == t) ? 1.0 : 0.0;
+                        g0[u] = xrec[offu + offl];
+                        g1[u] = xrec[stride + offu + offl];
+                    }
 #pragma unroll
-                            for (int sx = 0; sx < 2; sx++) gq[sx] = xrec[sx * stride + cP + dd * ni + t];
-                        } else {
-                            const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
-#pragma unroll
-                            for (int sx = 0; sx < 2; sx++) {
-                                const double* Pl = xrec + sx * stride + cPl + (dd - 6) * 2;
-                                const double p0 = Pl[0], p1 = Pl[1];
-                                gq[sx] = (t == c0) ? p0 : ((t == c1) ? p1 : 0.0);
-                            }
+                    for (int u = 0; u < 6; u++) {
+                        const double m0 = isind[u] ? one[u] : (take[u] ? g0[u] : 0.0);  // (1.0 * B_k is B_k exactly)
+                        const double m1 = isind[u] ? one[u] : (take[u] ? g1[u] : 0.0);
+                        if (LEG_G_ON(lane_on && j0 + u < nv)) {
+                            *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{m0 * W[0][0][0], m0 * W[0][0][1]}; LEG_G_THROTTLE
+                            *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{m1 * W[1][0][0], m1 * W[1][0][1]}; LEG_G_THROTTLE
                         }
-#pragma unroll
-                        for (int sx = 0; sx < 2; sx++)
-                            if (lane_on)
-                                *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * nv + j) * n) = v2d_t{gq[sx] * W[sx][0][0], gq[sx] * W[sx][0][1]};
                     }
                 }
                 for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * nv; r += LEG_BLOCK / ntail)
-                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
                         *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
             // -- RectangleSurfaceContactConstraints.cpp:52-93
             {
                 double* dst = base + ((size_t)off_contact + (size_t)ia * 7) * n;
+                double p[2][2][6];
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
                     const double* l = xrec + sx * stride + cL + t;
-                    double p[2][6];
 #pragma unroll
                     for (int q6 = 0; q6 < 6; q6++) {
                         const double l0 = l[q6 * ni], l1 = l[(6 + q6) * ni], l2 = l[(12 + q6) * ni];
-                        p[0][q6] = l0 * W[sx][0][0] + l1 * W[sx][1][0] + l2 * W[sx][2][0];
-                        p[1][q6] = l0 * W[sx][0][1] + l1 * W[sx][1][1] + l2 * W[sx][2][1];
+                        p[sx][0][q6] = l0 * W[sx][0][0] + l1 * W[sx][1][0] + l2 * W[sx][2][0];
+                        p[sx][1][q6] = l0 * W[sx][0][1] + l1 * W[sx][1][1] + l2 * W[sx][2][1];
                     }
+                }
+#pragma unroll
+                for (int sx = 0; sx < 2; sx++) {
                     const double* lam = xrec + sx * stride + clam;
 #pragma unroll
                     for (int rr = 0; rr < 7; rr++) {
-                        const double v0 = live ? contact_row(rr, lam, p[0], mu, gam, Lx, Ly) : 0.0;
-                        const double v1 = live ? contact_row(rr, lam, p[1], mu, gam, Lx, Ly) : 0.0;
-                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1};
+                        const double v0 = live ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
+                        const double v1 = live ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
+                        if (LEG_G_ON(lane_on)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
                     }
                 }
                 for (int r = tid / max(ntail, 1); ntail > 0 && r < 14; r += LEG_BLOCK / ntail)
-                    if (tid < (LEG_BLOCK / ntail) * ntail)
+                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
                         *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
             // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base]
             if (ncust > 0) {
                 double* dst = base + (size_t)off_cust * n;
+                auto bcast = [&](const double x, const int l) {
+                    const long long xi = __double_as_longlong(x);
+                    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(xi >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xi, l));
+                };
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
                     const int cnt = __builtin_amdgcn_readlane(cu_n, sx * LG);
                     const double* rs = xrec + sx * stride;
 #pragma unroll 1
-                    for (int r = 0; r < cnt; r++) {
-                        const int sl_ = sx * LG + r;
-                        const int row = __builtin_amdgcn_readlane(cu_row, sl_);
-                        const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
-                        const long long cai = __double_as_longlong(cu_ca), cbi = __double_as_longlong(cu_cb);
-                        const double ca = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(cai >> 32), sl_) << 32) | (unsigned)__builtin_amdgcn_readlane((int)cai, sl_));
-                        const double cb = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(cbi >> 32), sl_) << 32) | (unsigned)__builtin_amdgcn_readlane((int)cbi, sl_));
-                        const double da = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
-                        const double db = (qb < 0) ? 0.0 : rs[((qb < 6) ? cPsf + qb * ni : cP + (qb - 6) * ni) + t];
-                        const double cf = ca * da + cb * db;
-                        if (lane_on) *reinterpret_cast<v2d_t*>(dst + (size_t)row * n) = v2d_t{live ? cf * W[sx][0][0] : 0.0, live ? cf * W[sx][0][1] : 0.0};
+                    for (int r0 = 0; r0 < cnt; r0 += 4) {
+                        double da[4], db[4], ca[4], cb[4];
+                        int row[4];
+                        bool hasb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int sl_ = sx * LG + min(r0 + u, cnt - 1);
+                            row[u] = __builtin_amdgcn_readlane(cu_row, sl_);
+                            const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
+                            ca[u] = bcast(cu_ca, sl_);
+                            cb[u] = bcast(cu_cb, sl_);
+                            hasb[u] = qb >= 0;
+                            const int qbb = hasb[u] ? qb : 0;
+                            da[u] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
+                            db[u] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + t];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const double cf = ca[u] * da[u] + cb[u] * (hasb[u] ? db[u] : 0.0);
+                            if (LEG_G_ON(lane_on && r0 + u < cnt))
+                                *reinterpret_cast<v2d_t*>(dst + (size_t)row[u] * n) = v2d_t{live ? cf * W[sx][0][0] : 0.0, live ? cf * W[sx][0][1] : 0.0}; LEG_G_THROTTLE
+                        }
                     }
                 }
                 if (ntail > 0) {  // chunks 64.. of those rows: lane -> (sample, row of the sample, chunk)
@@ -1233,7 +1290,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const bool on = r < n0 + n1 && tid < per * ntail;
                         const int sl_ = on ? ((r < n0) ? r : LG + (r - n0)) : 0;
                         const int row = __shfl(cu_row, sl_);
-                        if (on) *reinterpret_cast<v2d_t*>(dst - cc + (size_t)row * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
+                        if (LEG_G_ON(on)) *reinterpret_cast<v2d_t*>(dst - cc + (size_t)row * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
                     }
                 }
             }
