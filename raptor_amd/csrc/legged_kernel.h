@@ -49,6 +49,16 @@
 #else
 #define LEG_G_ON(c) (c)
 #endif
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 3  // measurement builds: no tail chunks / no customized rows
+#define LEG_G_TAIL false
+#else
+#define LEG_G_TAIL true
+#endif
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 4
+#define LEG_G_CUST false
+#else
+#define LEG_G_CUST true
+#endif
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -1154,6 +1164,13 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             double* base = JAC + (size_t)ba * L.m * n + cc;
             // Every piece below works in blocks of rows: all LDS reads of a block are issued before the first of them is used (with two
             // wavefronts per SIMD nothing else hides an LDS round trip per row), rows past the end repeat the last row's reads and store nothing.
+            // A row is cpr 16-byte chunks, the wavefront stores 64 of them per instruction: the chunks beyond (structural zeros, ntail per
+            // row) follow right after their block -- left to the end of the piece they were 32-byte holes in lines that L2 had written
+            // back before the hole was filled (measured: the kernel is SLOWER without the tail stores, 1.24 -> 1.37 ms).
+            const int tl_u = (ntail > 0) ? tid / ntail : LEG_BLOCK, tl_c = (ntail > 0) ? 2 * (LEG_BLOCK + tid % ntail) - cc : 0;
+            auto tail_rows = [&](double* rows, const int count) {  // rows: address of the lane's chunk in the first row of the run
+                if (LEG_G_TAIL && ntail > 0 && LEG_G_ON(tl_u < count)) *reinterpret_cast<v2d_t*>(rows + (size_t)tl_u * n + tl_c) = zero2;
+            };
             // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
             {
                 double* dst = base + ((size_t)off_tau + (size_t)ia * ni) * n;
@@ -1175,11 +1192,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                             const double v1 = d0[u] * B01 + d1[u] * B11 + d2[u] * B21;
                             if (LEG_G_ON(lane_on && r0 + u < ni)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + r0 + u) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
                         }
+                        tail_rows(dst + (size_t)(sx * ni + r0) * n, min(6, ni - r0));
                     }
                 }
-                for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * ni; r += LEG_BLOCK / ntail)
-                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
-                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
             // -- ConstrainedJointLimits.cpp:59-68: row j is B_k at the joint's own column (independent joint) or P_dep(j, t) B_k
             {
@@ -1204,19 +1219,20 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         g0[u] = xrec[offu + offl];
                         g1[u] = xrec[stride + offu + offl];
                     }
+                    const int cnt = min(6, nv - j0);
 #pragma unroll
                     for (int u = 0; u < 6; u++) {
                         const double m0 = isind[u] ? one[u] : (take[u] ? g0[u] : 0.0);  // (1.0 * B_k is B_k exactly)
-                        const double m1 = isind[u] ? one[u] : (take[u] ? g1[u] : 0.0);
-                        if (LEG_G_ON(lane_on && j0 + u < nv)) {
-                            *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{m0 * W[0][0][0], m0 * W[0][0][1]}; LEG_G_THROTTLE
-                            *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{m1 * W[1][0][0], m1 * W[1][0][1]}; LEG_G_THROTTLE
-                        }
+                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{m0 * W[0][0][0], m0 * W[0][0][1]}; LEG_G_THROTTLE
                     }
+                    tail_rows(dst + (size_t)j0 * n, cnt);
+#pragma unroll
+                    for (int u = 0; u < 6; u++) {
+                        const double m1 = isind[u] ? one[u] : (take[u] ? g1[u] : 0.0);
+                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{m1 * W[1][0][0], m1 * W[1][0][1]}; LEG_G_THROTTLE
+                    }
+                    tail_rows(dst + (size_t)(nv + j0) * n, cnt);
                 }
-                for (int r = tid / max(ntail, 1); ntail > 0 && r < 2 * nv; r += LEG_BLOCK / ntail)
-                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
-                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
             // -- RectangleSurfaceContactConstraints.cpp:52-93
             {
@@ -1241,56 +1257,49 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const double v1 = live ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
                         if (LEG_G_ON(lane_on)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
                     }
+                    tail_rows(dst + (size_t)(sx * 7) * n, 7);
                 }
-                for (int r = tid / max(ntail, 1); ntail > 0 && r < 14; r += LEG_BLOCK / ntail)
-                    if (LEG_G_ON(tid < (LEG_BLOCK / ntail) * ntail))
-                        *reinterpret_cast<v2d_t*>(dst - cc + (size_t)r * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
             }
-            // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base]
-            if (ncust > 0) {
+            // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base].
+            // The block is ordered by quantity, then sample: the rows of one quantity at these two samples are adjacent, so the walk is
+            // quantity-major -- two quantities x two samples per block, each pair of adjacent rows stored back to back.
+            if (LEG_G_CUST && ncust > 0) {
                 double* dst = base + (size_t)off_cust * n;
                 auto bcast = [&](const double x, const int l) {
                     const long long xi = __double_as_longlong(x);
                     return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(xi >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xi, l));
                 };
-#pragma unroll
-                for (int sx = 0; sx < 2; sx++) {
-                    const int cnt = __builtin_amdgcn_readlane(cu_n, sx * LG);
-                    const double* rs = xrec + sx * stride;
+                const int n0 = __builtin_amdgcn_readlane(cu_n, 0), n1 = __builtin_amdgcn_readlane(cu_n, LG);
 #pragma unroll 1
-                    for (int r0 = 0; r0 < cnt; r0 += 4) {
-                        double da[4], db[4], ca[4], cb[4];
-                        int row[4];
-                        bool hasb[4];
+                for (int r0 = 0; r0 < max(n0, n1); r0 += 2) {
+                    double da[4], db[4], ca[4], cb[4];
+                    int row[4];
+                    bool hasb[4], on[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int sl_ = sx * LG + min(r0 + u, cnt - 1);
-                            row[u] = __builtin_amdgcn_readlane(cu_row, sl_);
-                            const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
-                            ca[u] = bcast(cu_ca, sl_);
-                            cb[u] = bcast(cu_cb, sl_);
-                            hasb[u] = qb >= 0;
-                            const int qbb = hasb[u] ? qb : 0;
-                            da[u] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
-                            db[u] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + t];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const double cf = ca[u] * da[u] + cb[u] * (hasb[u] ? db[u] : 0.0);
-                            if (LEG_G_ON(lane_on && r0 + u < cnt))
-                                *reinterpret_cast<v2d_t*>(dst + (size_t)row[u] * n) = v2d_t{live ? cf * W[sx][0][0] : 0.0, live ? cf * W[sx][0][1] : 0.0}; LEG_G_THROTTLE
-                        }
+                    for (int w = 0; w < 4; w++) {  // w = 2 * (quantity of the block) + sample
+                        const int sx = w & 1, r = r0 + (w >> 1), cnt = sx ? n1 : n0;
+                        on[w] = r < cnt;
+                        const int sl_ = sx * LG + (on[w] ? r : 0);
+                        row[w] = __builtin_amdgcn_readlane(cu_row, sl_);
+                        const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
+                        ca[w] = bcast(cu_ca, sl_);
+                        cb[w] = bcast(cu_cb, sl_);
+                        hasb[w] = qb >= 0;
+                        const int qbb = hasb[w] ? qb : 0;
+                        const double* rs = xrec + sx * stride;
+                        da[w] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
+                        db[w] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + t];
                     }
-                }
-                if (ntail > 0) {  // chunks 64.. of those rows: lane -> (sample, row of the sample, chunk)
-                    const int per = LEG_BLOCK / ntail;  // rows per store
-                    const int n0 = __builtin_amdgcn_readlane(cu_n, 0), n1 = __builtin_amdgcn_readlane(cu_n, LG);
-                    for (int rb = 0; rb < n0 + n1; rb += per) {  // (uniform trip count: the shuffle below needs every lane)
-                        const int r = rb + tid / ntail;
-                        const bool on = r < n0 + n1 && tid < per * ntail;
-                        const int sl_ = on ? ((r < n0) ? r : LG + (r - n0)) : 0;
-                        const int row = __shfl(cu_row, sl_);
-                        if (LEG_G_ON(on)) *reinterpret_cast<v2d_t*>(dst - cc + (size_t)row * n + 2 * (LEG_BLOCK + tid % ntail)) = zero2;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const double cf = ca[w] * da[w] + cb[w] * (hasb[w] ? db[w] : 0.0);
+                        if (LEG_G_ON(lane_on && on[w]))
+                            *reinterpret_cast<v2d_t*>(dst + (size_t)row[w] * n) = v2d_t{live ? cf * W[w & 1][0][0] : 0.0, live ? cf * W[w & 1][0][1] : 0.0}; LEG_G_THROTTLE
+                    }
+                    if (LEG_G_TAIL && ntail > 0) {
+                        const int rw = (tl_u == 0) ? row[0] : ((tl_u == 1) ? row[1] : ((tl_u == 2) ? row[2] : row[3]));
+                        const bool ok = (tl_u == 0) ? on[0] : ((tl_u == 1) ? on[1] : ((tl_u == 2) ? on[2] : (tl_u == 3 && on[3])));
+                        if (LEG_G_ON(ok)) *reinterpret_cast<v2d_t*>(dst + (size_t)rw * n + tl_c) = zero2;
                     }
                 }
             }
