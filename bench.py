@@ -103,9 +103,16 @@ class Legged:
     batch = 1024
     bytes_per_se = None                   # 8 (rows / N) (n + 1): every row the expand kernel writes, once, g and pg_pz
     flops_per_se = 230000                 # SURVEY.md 8d total for Talos / G1 as the reference does it
-    kernels = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows) + legged_period_kernel (reset-map rows)",
-               "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
-    pmc_keys = ["legged_core_kernel<16, true>", "legged_expand_kernel"]
+    # fused form (round 3): the core kernel writes every pg_pz row of the torque / joint-limit / contact / customized blocks itself
+    kernels = [None,
+               "legged_core_kernel<16,true,fused> (trajectory + re-rooted RNEA + analytic derivatives + g rows + records, then the pg_pz rows of "
+               "the torque / joint-limit / contact / customized blocks in Optimizer order)",
+               "legged_period_kernel (reset-map rows)"]
+    rows_kernel = 1
+    pmc_keys = [None, "legged_core_kernel<16, true, true, false>", "legged_period_kernel<18, 6, true>"]
+    kernels_unfused = ["legged_core_kernel<16,true> (trajectory + re-rooted RNEA + analytic derivatives + g rows) + legged_period_kernel (reset-map rows)",
+                       "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]
+    pmc_keys_unfused = ["legged_core_kernel<16, true>", "legged_expand_kernel"]
     bound = "hbm"
     z_scale = 0.1  # TalosSingleStep.cpp:61
 
@@ -135,7 +142,7 @@ class Digit:
                "torque / joint-limit / contact / customized blocks in Optimizer order)",
                "digit_period_loops_kernel + legged_period_kernel (reset-map rows)"]
     rows_kernel = 1
-    pmc_keys = ["digit_loops_both_kernel", "legged_core_kernel<32, true, true>", "legged_period_kernel<36, 24, true>"]
+    pmc_keys = ["digit_loops_both_kernel", "legged_core_kernel<32, true, true, true>", "legged_period_kernel<36, 24, true>"]
     kernels_unfused = ["digit_loops_both_kernel (knee + toe) + legged_core_kernel<32,true> (closed loops, re-rooted RNEA, analytic derivatives, g rows) "
                        "+ digit_period_loops_kernel + legged_period_kernel (reset-map rows)",
                        "legged_expand_kernel (pg_pz rows in Optimizer order from the per-sample records)"]

@@ -37,27 +37,12 @@
 #ifndef LEG_STAGGER
 #define LEG_STAGGER 4     // fused core kernel: start offset between the hardware slots of a CU, in s_sleep(127) units (measured 2 / 4 / 8 / 16)
 #endif
-// fused core kernel, phase G: at most this many of a wavefront's stores in flight (s_waitcnt vmcnt): the CU's vector-memory path is
-// in order, so the loads of the wavefronts that compute wait behind whatever the storing wavefronts have queued
-#ifdef LEG_G_VMCNT
-#define LEG_G_THROTTLE __builtin_amdgcn_s_waitcnt(((LEG_G_VMCNT) & 15) | (7 << 4) | (15 << 8) | (((LEG_G_VMCNT) >> 4) << 14));
-#else
-#define LEG_G_THROTTLE
-#endif
-#if defined(LEG_G_PROBE) && LEG_G_PROBE == 1  // measurement build: phase G without its stores (one lane in 2^20 keeps the values alive)
+// Measurement builds of the fused core kernel's phase G: -DLEG_G_PROBE=1 drops its stores (one lane in 2^20 keeps the
+// values alive), =2 ends the phase after the records are back in LDS.
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 1
 #define LEG_G_ON(c) ((c) && (tid + (int)blockIdx.x * 64) % 1048576 == 12345)
 #else
 #define LEG_G_ON(c) (c)
-#endif
-#if defined(LEG_G_PROBE) && LEG_G_PROBE == 3  // measurement builds: no tail chunks / no customized rows
-#define LEG_G_TAIL false
-#else
-#define LEG_G_TAIL true
-#endif
-#if defined(LEG_G_PROBE) && LEG_G_PROBE == 4
-#define LEG_G_CUST false
-#else
-#define LEG_G_CUST true
 #endif
 #define LEG_LOC 18        // per-joint local transform for the kinematic walk: X (9), t (3), axis (3), qd, qdd, rev
 
@@ -252,7 +237,7 @@ RD void legged_expand_cust(const int tid, const int n, const int ndyn, const int
 #else
 #define LEG_PHASE_END(k, expr)
 #endif
-template <int LG, bool DERIV, bool FUSE = false>
+template <int LG, bool DERIV, bool FUSE = false, bool KEVEN = true>
 __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const DevModel* __restrict__ M, const DevTraj* __restrict__ T, const DevLegged* __restrict__ Q,
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
@@ -1079,24 +1064,32 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll 1
     for (int idx = 0; idx < nflat; idx++) f2_step(idx, f2_fetch(idx));
 
-    // ---- phase G (FUSE builds): the torque / joint-limit / contact rows of pg_pz of this wavefront's sample-evals, straight from its
-    // own records.  The expansion is bound by the write path and this kernel by fp64 issue: in one kernel the stores of one wavefront
-    // drain while the other wavefront of the SIMD computes, which two launches (or two streams: the core kernel holds all of a CU's LDS)
-    // never did.  With two wavefronts per SIMD nothing hides a chain of dependent LDS look-ups per element (the flat element loop of
+    // ---- phase G (FUSE builds): every row of pg_pz but the reset map's, straight from this wavefront's own records.  The expansion is
+    // bound by the write path and the phases above by fp64 issue: in one kernel the stores of one wavefront drain while the other
+    // wavefront of the SIMD computes, which two launches (or two streams: the core kernel holds all of a CU's LDS) never did.
+    // With two wavefronts per SIMD nothing hides a chain of dependent LDS look-ups per element (the flat element loop of
     // legged_expand_kernel run here took 0.97 ms on top of the core kernel's 0.66), so the mapping is lane = FIXED 16-byte column chunk:
-    // the lane's actuator and its six Bernstein weights per sample live in registers, a row costs 1-3 LDS reads at constant offsets,
-    // a few FMAs and one store.  Host conditions (legged_can_fuse): N even (a pair of sample-evals = consecutive samples of ONE decision
-    // vector), n and K even (a chunk's two columns belong to one actuator), ni * K <= 128 (chunks 64.. of a row are structural zeros),
-    // n <= 256, two records fit the wavefront's LDS area.  The customized block (ordered by quantity, then sample) stays with
-    // legged_expand_kernel, which then writes nothing else.
+    // the actuator(s) of the lane's two columns and their Bernstein weights per sample live in registers, a row costs 1-3 LDS reads at
+    // constant offsets, a few FMAs and one store.  KEVEN (K even): both columns of a chunk belong to one actuator and share the reads.
+    // Host conditions (legged_can_fuse): N even (a pair of sample-evals = consecutive samples of ONE decision vector), n even,
+    // ni * K <= 128 (chunks 64.. of a row are structural zeros), n <= 256, two records fit the wavefront's LDS area, a sample has at most
+    // LG customized rows.  Pairs of sample-evals are expanded one after the other (LG = 16: two pairs per wavefront).
     if constexpr (FUSE) {
+        constexpr int NH = KEVEN ? 1 : 2;  // distinct actuators a chunk can touch
+        constexpr int RB = KEVEN ? 6 : 4;  // rows per block of the joint-limit piece (its per-row state doubles with NH)
         const int stride = Q->c_stride, K = Q->K, n = L.n;
         const int ndyn = ni * K, cpr = n >> 1;
         const int ntail = cpr - LEG_BLOCK;  // chunks of a row beyond the wavefront's 64 (> 0 for Digit: 66 chunks)
         const int cc = 2 * tid;
-        const bool live = cc < ndyn;
         const bool lane_on = tid < cpr;
-        const int t = live ? cc / K : 0, kk = live ? cc - t * K : 0;
+        bool lv[2];
+        int th[2], kh[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            lv[h] = cc + h < ndyn;
+            th[h] = lv[h] ? (cc + h) / K : 0;
+            kh[h] = lv[h] ? cc + h - th[h] * K : 0;
+        }
         const int cD = Q->c_D, cP = Q->c_P, cPl = Q->c_Pl, cL = Q->c_L, clam = Q->c_lam;
         const int off_tau = Q->off_tau, off_q = Q->off_q, off_contact = Q->off_contact;
         const v2d_t zero2 = v2d_t{0.0, 0.0};
@@ -1120,12 +1113,13 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             long long ba = b0;
             while (ia >= N) { ia -= N; ba++; }
             wave_sync();  // the record stores above and the loads below are one wavefront's vector-memory operations: performed in order
-            // customized rows of these two samples: lane g of group sx holds the g-th row of sample ia + sx (host: <= LG rows per sample)
+            // customized rows of these two samples: lane g of lane group 2 rd + sx holds the g-th row of sample ia + sx
+            const int l0 = 2 * rd * LG;  // first lane of the pair's two lane groups
             int cu_row = 0, cu_qa = 0, cu_qb = -1, cu_n = 0;
             double cu_ca = 0.0, cu_cb = 0.0;
-            if (ncust > 0) {
-                const int cs = cust_start[ia + eg];
-                cu_n = cust_start[ia + eg + 1] - cs;
+            if (ncust > 0 && (eg >> 1) == rd) {
+                const int cs = cust_start[ia + (eg & 1)];
+                cu_n = cust_start[ia + (eg & 1) + 1] - cs;
                 if (g < cu_n) {
                     cu_row = cust_list[cs + g];
                     const DevCustRow cr = cust[cu_row];
@@ -1136,11 +1130,12 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
             for (int sx = 0; sx < 2; sx++)
 #pragma unroll
-                for (int o = 0; o < 3; o++) {
-                    const double* Bs = basis + (size_t)((ia + sx) * 3 + o) * K + kk;
-                    W[sx][o][0] = live ? Bs[0] : 0.0;
-                    W[sx][o][1] = live ? Bs[1] : 0.0;
-                }
+                for (int o = 0; o < 3; o++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const double w = basis[(size_t)((ia + sx) * 3 + o) * K + kh[h]];
+                        W[sx][o][h] = lv[h] ? w : 0.0;
+                    }
             {   // the two records back from L2, 16 bytes per lane and seven loads in flight (one load per trip of a plain loop is a chain of
                 // ~28 L2 round trips: 0.16 ms of the launch)
                 const v2d_t* src2 = reinterpret_cast<const v2d_t*>(core + (size_t)ea * stride);
@@ -1166,31 +1161,32 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             // wavefronts per SIMD nothing else hides an LDS round trip per row), rows past the end repeat the last row's reads and store nothing.
             // A row is cpr 16-byte chunks, the wavefront stores 64 of them per instruction: the chunks beyond (structural zeros, ntail per
             // row) follow right after their block -- left to the end of the piece they were 32-byte holes in lines that L2 had written
-            // back before the hole was filled (measured: the kernel is SLOWER without the tail stores, 1.24 -> 1.37 ms).
+            // back before the hole was filled (measured: the kernel is SLOWER without the tail stores, 1.24 -> 1.37 ms; after every row
+            // instead of every block: 1.18 -> 1.22 ms).
             const int tl_u = (ntail > 0) ? tid / ntail : LEG_BLOCK, tl_c = (ntail > 0) ? 2 * (LEG_BLOCK + tid % ntail) - cc : 0;
             auto tail_rows = [&](double* rows, const int count) {  // rows: address of the lane's chunk in the first row of the run
-                if (LEG_G_TAIL && ntail > 0 && LEG_G_ON(tl_u < count)) *reinterpret_cast<v2d_t*>(rows + (size_t)tl_u * n + tl_c) = zero2;
+                if (ntail > 0 && LEG_G_ON(tl_u < count)) *reinterpret_cast<v2d_t*>(rows + (size_t)tl_u * n + tl_c) = zero2;
             };
             // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
             {
                 double* dst = base + ((size_t)off_tau + (size_t)ia * ni) * n;
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
-                    const double* d = xrec + sx * stride + cD + (t * 3) * ni;
-                    const double B00 = W[sx][0][0], B01 = W[sx][0][1], B10 = W[sx][1][0], B11 = W[sx][1][1], B20 = W[sx][2][0], B21 = W[sx][2][1];
+                    const double* dh[2] = {xrec + sx * stride + cD + (th[0] * 3) * ni, xrec + sx * stride + cD + (th[1] * 3) * ni};
 #pragma unroll 1
                     for (int r0 = 0; r0 < ni; r0 += 6) {
-                        double d0[6], d1[6], d2[6];
+                        double d0[6][NH], d1[6][NH], d2[6][NH];
 #pragma unroll
                         for (int u = 0; u < 6; u++) {
                             const int rr = min(r0 + u, ni - 1);
-                            d0[u] = d[rr]; d1[u] = d[ni + rr]; d2[u] = d[2 * ni + rr];
+#pragma unroll
+                            for (int h = 0; h < NH; h++) { d0[u][h] = dh[h][rr]; d1[u][h] = dh[h][ni + rr]; d2[u][h] = dh[h][2 * ni + rr]; }
                         }
 #pragma unroll
                         for (int u = 0; u < 6; u++) {
-                            const double v0 = d0[u] * B00 + d1[u] * B10 + d2[u] * B20;
-                            const double v1 = d0[u] * B01 + d1[u] * B11 + d2[u] * B21;
-                            if (LEG_G_ON(lane_on && r0 + u < ni)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + r0 + u) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
+                            const double v0 = d0[u][0] * W[sx][0][0] + d1[u][0] * W[sx][1][0] + d2[u][0] * W[sx][2][0];
+                            const double v1 = d0[u][NH - 1] * W[sx][0][1] + d1[u][NH - 1] * W[sx][1][1] + d2[u][NH - 1] * W[sx][2][1];
+                            if (LEG_G_ON(lane_on && r0 + u < ni)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + r0 + u) * n) = v2d_t{lv[0] ? v0 : 0.0, lv[1] ? v1 : 0.0};
                         }
                         tail_rows(dst + (size_t)(sx * ni + r0) * n, min(6, ni - r0));
                     }
@@ -1200,11 +1196,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             {
                 double* dst = base + ((size_t)off_q + (size_t)ia * nv) * n;
 #pragma unroll 1
-                for (int j0 = 0; j0 < nv; j0 += 6) {
-                    double g0[6], g1[6], one[6];
-                    bool isind[6], take[6];
+                for (int j0 = 0; j0 < nv; j0 += RB) {
+                    double g0[RB][NH], g1[RB][NH], one[RB][NH];
+                    bool isind[RB], take[RB][NH];
 #pragma unroll
-                    for (int u = 0; u < 6; u++) {
+                    for (int u = 0; u < RB; u++) {
                         const int j = min(j0 + u, nv - 1);
                         const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
                         const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
@@ -1213,23 +1209,26 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const bool isbase = dd < 6;
                         // one unconditional read per sample from an address every lane may read: an independent row reads entry 0 and drops it
                         const int offu = isind[u] ? 0 : (isbase ? cP + dd * ni : cPl + (dd - 6) * 2);
-                        const int offl = isind[u] ? 0 : (isbase ? t : ((t == c0) ? 0 : 1));
-                        take[u] = isbase || t == c0 || t == c1;
-                        one[u] = (live && info == t) ? 1.0 : 0.0;
-                        g0[u] = xrec[offu + offl];
-                        g1[u] = xrec[stride + offu + offl];
-                    }
-                    const int cnt = min(6, nv - j0);
 #pragma unroll
-                    for (int u = 0; u < 6; u++) {
-                        const double m0 = isind[u] ? one[u] : (take[u] ? g0[u] : 0.0);  // (1.0 * B_k is B_k exactly)
-                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{m0 * W[0][0][0], m0 * W[0][0][1]}; LEG_G_THROTTLE
+                        for (int h = 0; h < NH; h++) {
+                            const int offl = isind[u] ? 0 : (isbase ? th[h] : ((th[h] == c0) ? 0 : 1));
+                            take[u][h] = isbase || th[h] == c0 || th[h] == c1;
+                            one[u][h] = (info == th[h]) ? 1.0 : 0.0;  // (a dead column's weight is zero)
+                            g0[u][h] = xrec[offu + offl];
+                            g1[u][h] = xrec[stride + offu + offl];
+                        }
+                    }
+                    const int cnt = min(RB, nv - j0);
+#pragma unroll
+                    for (int u = 0; u < RB; u++) {  // (1.0 * B_k is B_k exactly)
+                        const double ma = isind[u] ? one[u][0] : (take[u][0] ? g0[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g0[u][NH - 1] : 0.0);
+                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{lv[0] ? ma * W[0][0][0] : 0.0, lv[1] ? mb * W[0][0][1] : 0.0};
                     }
                     tail_rows(dst + (size_t)j0 * n, cnt);
 #pragma unroll
-                    for (int u = 0; u < 6; u++) {
-                        const double m1 = isind[u] ? one[u] : (take[u] ? g1[u] : 0.0);
-                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{m1 * W[1][0][0], m1 * W[1][0][1]}; LEG_G_THROTTLE
+                    for (int u = 0; u < RB; u++) {
+                        const double ma = isind[u] ? one[u][0] : (take[u][0] ? g1[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g1[u][NH - 1] : 0.0);
+                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{lv[0] ? ma * W[1][0][0] : 0.0, lv[1] ? mb * W[1][0][1] : 0.0};
                     }
                     tail_rows(dst + (size_t)(nv + j0) * n, cnt);
                 }
@@ -1239,23 +1238,26 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 double* dst = base + ((size_t)off_contact + (size_t)ia * 7) * n;
                 double p[2][2][6];
 #pragma unroll
-                for (int sx = 0; sx < 2; sx++) {
-                    const double* l = xrec + sx * stride + cL + t;
+                for (int sx = 0; sx < 2; sx++)
 #pragma unroll
                     for (int q6 = 0; q6 < 6; q6++) {
-                        const double l0 = l[q6 * ni], l1 = l[(6 + q6) * ni], l2 = l[(12 + q6) * ni];
-                        p[sx][0][q6] = l0 * W[sx][0][0] + l1 * W[sx][1][0] + l2 * W[sx][2][0];
-                        p[sx][1][q6] = l0 * W[sx][0][1] + l1 * W[sx][1][1] + l2 * W[sx][2][1];
+                        double lq[3][NH];
+#pragma unroll
+                        for (int h = 0; h < NH; h++) {
+                            const double* l = xrec + sx * stride + cL + th[h];
+                            lq[0][h] = l[q6 * ni]; lq[1][h] = l[(6 + q6) * ni]; lq[2][h] = l[(12 + q6) * ni];
+                        }
+                        p[sx][0][q6] = lq[0][0] * W[sx][0][0] + lq[1][0] * W[sx][1][0] + lq[2][0] * W[sx][2][0];
+                        p[sx][1][q6] = lq[0][NH - 1] * W[sx][0][1] + lq[1][NH - 1] * W[sx][1][1] + lq[2][NH - 1] * W[sx][2][1];
                     }
-                }
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
                     const double* lam = xrec + sx * stride + clam;
 #pragma unroll
                     for (int rr = 0; rr < 7; rr++) {
-                        const double v0 = live ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
-                        const double v1 = live ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
-                        if (LEG_G_ON(lane_on)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1}; LEG_G_THROTTLE
+                        const double v0 = lv[0] ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
+                        const double v1 = lv[1] ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
+                        if (LEG_G_ON(lane_on)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1};
                     }
                     tail_rows(dst + (size_t)(sx * 7) * n, 7);
                 }
@@ -1263,23 +1265,23 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base].
             // The block is ordered by quantity, then sample: the rows of one quantity at these two samples are adjacent, so the walk is
             // quantity-major -- two quantities x two samples per block, each pair of adjacent rows stored back to back.
-            if (LEG_G_CUST && ncust > 0) {
+            if (ncust > 0) {
                 double* dst = base + (size_t)off_cust * n;
                 auto bcast = [&](const double x, const int l) {
                     const long long xi = __double_as_longlong(x);
                     return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(xi >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xi, l));
                 };
-                const int n0 = __builtin_amdgcn_readlane(cu_n, 0), n1 = __builtin_amdgcn_readlane(cu_n, LG);
+                const int n0 = __builtin_amdgcn_readlane(cu_n, l0), n1 = __builtin_amdgcn_readlane(cu_n, l0 + LG);
 #pragma unroll 1
                 for (int r0 = 0; r0 < max(n0, n1); r0 += 2) {
-                    double da[4], db[4], ca[4], cb[4];
+                    double da[4][NH], db[4][NH], ca[4], cb[4];
                     int row[4];
                     bool hasb[4], on[4];
 #pragma unroll
                     for (int w = 0; w < 4; w++) {  // w = 2 * (quantity of the block) + sample
                         const int sx = w & 1, r = r0 + (w >> 1), cnt = sx ? n1 : n0;
                         on[w] = r < cnt;
-                        const int sl_ = sx * LG + (on[w] ? r : 0);
+                        const int sl_ = l0 + sx * LG + (on[w] ? r : 0);
                         row[w] = __builtin_amdgcn_readlane(cu_row, sl_);
                         const int qa = __builtin_amdgcn_readlane(cu_qa, sl_), qb = __builtin_amdgcn_readlane(cu_qb, sl_);
                         ca[w] = bcast(cu_ca, sl_);
@@ -1287,16 +1289,20 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         hasb[w] = qb >= 0;
                         const int qbb = hasb[w] ? qb : 0;
                         const double* rs = xrec + sx * stride;
-                        da[w] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + t];
-                        db[w] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + t];
+#pragma unroll
+                        for (int h = 0; h < NH; h++) {
+                            da[w][h] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + th[h]];
+                            db[w][h] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + th[h]];
+                        }
                     }
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
-                        const double cf = ca[w] * da[w] + cb[w] * (hasb[w] ? db[w] : 0.0);
+                        const double cfa = ca[w] * da[w][0] + cb[w] * (hasb[w] ? db[w][0] : 0.0);
+                        const double cfb = ca[w] * da[w][NH - 1] + cb[w] * (hasb[w] ? db[w][NH - 1] : 0.0);
                         if (LEG_G_ON(lane_on && on[w]))
-                            *reinterpret_cast<v2d_t*>(dst + (size_t)row[w] * n) = v2d_t{live ? cf * W[w & 1][0][0] : 0.0, live ? cf * W[w & 1][0][1] : 0.0}; LEG_G_THROTTLE
+                            *reinterpret_cast<v2d_t*>(dst + (size_t)row[w] * n) = v2d_t{lv[0] ? cfa * W[w & 1][0][0] : 0.0, lv[1] ? cfb * W[w & 1][0][1] : 0.0};
                     }
-                    if (LEG_G_TAIL && ntail > 0) {
+                    if (ntail > 0) {
                         const int rw = (tl_u == 0) ? row[0] : ((tl_u == 1) ? row[1] : ((tl_u == 2) ? row[2] : row[3]));
                         const bool ok = (tl_u == 0) ? on[0] : ((tl_u == 1) ? on[1] : ((tl_u == 2) ? on[2] : (tl_u == 3 && on[3])));
                         if (LEG_G_ON(ok)) *reinterpret_cast<v2d_t*>(dst + (size_t)rw * n + tl_c) = zero2;

@@ -688,11 +688,13 @@ void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, 
 // fused form (round 3): the wide core kernel also writes the torque / joint-limit / contact rows of pg_pz (phase G) -- only the
 // customized block is left for legged_expand_kernel
 bool legged_can_fuse(const raptor_problem& p, const double* dJ) {
-    static const bool no_fuse = std::getenv("RAPTOR_NO_FUSE") != nullptr;
+    const bool no_fuse = std::getenv("RAPTOR_NO_FUSE") != nullptr;  // read per call: the tests and A/B scripts switch between the two forms
     const int ndyn = p.hleg.ni * p.hleg.K;
-    if (no_fuse || p.hleg.nb <= 16 || p.htraj.N % 2 != 0 || p.layout.n % 2 != 0 || p.hleg.K % 2 != 0 || ((size_t)dJ & 15) != 0) return false;
-    if (ndyn > 2 * LEG_BLOCK || p.layout.n > 4 * LEG_BLOCK || p.layout.n < ndyn || p.cust_max_per_sample > 32) return false;
-    return (size_t)2 * p.hleg.c_stride <= (size_t)2 * LegLds<32>::STRIDE;
+    const int LG = p.hleg.nb > 16 ? 32 : 16;
+    if (no_fuse || p.htraj.N % 2 != 0 || p.layout.n % 2 != 0 || ((size_t)dJ & 15) != 0) return false;
+    if (ndyn > 2 * LEG_BLOCK || p.layout.n > 4 * LEG_BLOCK || p.layout.n < ndyn || p.cust_max_per_sample > LG) return false;
+    const size_t area = (size_t)(LEG_BLOCK / LG) * (LG == 32 ? LegLds<32>::STRIDE : LegLds<16>::STRIDE);  // doubles per wavefront
+    return (size_t)2 * p.hleg.c_stride <= area;
 }
 
 // wavefronts of the fused core kernel resident at once on the current device (8 one-wavefront workgroups per CU: LDS and registers)
@@ -734,10 +736,18 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
                        p.d_cust_start.p, dG, p.s_core.p, d_lamrec)
-    if (wide && deriv && dJ_fused != nullptr) {
-        hipLaunchKernelGGL((legged_core_kernel<32, true, true>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p, p.d_traj.p,
-                           p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p, p.d_cust_start.p, dG,
-                           p.s_core.p, d_lamrec, dJ_fused, fused_first_round());
+#define LEG_LAUNCH_FUSED(LGV, KE)                                                                                            \
+    hipLaunchKernelGGL((legged_core_kernel<LGV, true, true, KE>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,       \
+                       p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,                 \
+                       p.d_cust_start.p, dG, p.s_core.p, d_lamrec, dJ_fused, stagger)
+    if (deriv && dJ_fused != nullptr) {
+        const bool keven = p.hleg.K % 2 == 0;
+        // the staggered start (up to ~0.1 ms for the last slot) pays once the launch has a steady state: at least four rounds of wavefronts
+        const int first = fused_first_round();
+        const int stagger = ((long long)grid >= 4LL * first) ? first : 0;
+        if (wide) { if (keven) LEG_LAUNCH_FUSED(32, true); else LEG_LAUNCH_FUSED(32, false); }
+        else { if (keven) LEG_LAUNCH_FUSED(16, true); else LEG_LAUNCH_FUSED(16, false); }
+#undef LEG_LAUNCH_FUSED
     } else if (wide) {
         if (deriv) LEG_LAUNCH(32, true); else LEG_LAUNCH(32, false);
     } else {

@@ -567,6 +567,49 @@ def test_legged_sample_counts(oracle, hip, which, N):
     check_blocks(Gh, Jh, Go, Jo, po)
 
 
+@pytest.mark.parametrize("which,N,B", [("g1", 14, 5), ("talos", 2, 3), ("g1", 16, 2), ("digit", 14, 5), ("digit", 2, 1), ("digit", 16, 3)])
+def test_legged_fused_rows_against_two_kernel_form(oracle, hip, which, N, B, monkeypatch):
+    """Even sample counts take the fused form (the core kernel writes the pg_pz rows of its own sample-evals); RAPTOR_NO_FUSE=1 (read
+    per call) keeps the record kernel + legged_expand_kernel.  Both forms against the oracle and against each other, on a Jacobian
+    buffer pre-filled with NaN (every entry must be written, structural zeros included), with batches that leave the last wavefront
+    of the LG = 16 kernel half empty (E = B N = 2 mod 4)."""
+    import torch
+
+    keep = []
+    if which == "digit":
+        po, m, cfg = H.digit_problem(oracle, keep, N=N, customized=True, periodic=True)
+        ph, _, _ = H.digit_problem(hip, keep, N=N, customized=True, periodic=True)
+        scale = 0.1
+    else:
+        po, m, cfg = H.legged_problem(oracle, which, keep, N=N, customized=True, periodic=True)
+        ph, _, _ = H.legged_problem(hip, which, keep, N=N, customized=True, periodic=True)
+        scale = 0.3
+    rng = np.random.default_rng(20250601 + N + B)
+    Z = scale * rng.uniform(-1, 1, (B, po.n))
+    Go, Jo = po.eval_host(Z)
+    Zd = torch.from_numpy(Z).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for form in ("fused", "two_kernel"):
+        if form == "two_kernel":
+            monkeypatch.setenv("RAPTOR_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("RAPTOR_NO_FUSE", raising=False)
+        G = torch.full((B, ph.m), float("nan"), dtype=torch.float64, device="cuda")
+        J = torch.full((B, ph.m, ph.n), float("nan"), dtype=torch.float64, device="cuda")
+        ph.eval_device(Zd.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G.data_ptr(), J.data_ptr(), st)
+        torch.cuda.synchronize()
+        out[form] = (G.cpu().numpy(), J.cpu().numpy())
+        check(out[form][0], Go)
+        check(out[form][1], Jo)
+        check_blocks(out[form][0], out[form][1], Go, Jo, po)
+    monkeypatch.delenv("RAPTOR_NO_FUSE", raising=False)
+    assert np.array_equal(out["fused"][0], out["two_kernel"][0])
+    Jf, Jt = out["fused"][1], out["two_kernel"][1]
+    assert np.array_equal(Jf == 0.0, Jt == 0.0)  # the same structural zeros
+    assert np.max(np.abs(Jf - Jt)) <= 1e-13 * max(1.0, np.max(np.abs(Jt)))
+
+
 def test_digit_eval_g_and_jac(oracle, hip):
     """eval_g / eval_jac_g of DigitSingleStepOptimizer's first three blocks at the example's size (N = 14, degree 5)."""
     keep = []
