@@ -130,6 +130,13 @@ RD double contact_row(int r, const double* lam, const double* p, double mu, doub
 //   row(., t*K + k) = D_q(., t) B_k + D_v(., t) dB_k + D_a(., t) ddB_k     (BezierCurves.cpp:165-169 chained into
 //   TorqueLimits.cpp:36-40, ConstrainedJointLimits.cpp:59-68, RectangleSurfaceContactConstraints.cpp:52-93)
 // 16-byte store of two adjacent columns
+RD void g_st(double* p, const v2d_t v) {  // phase G of the fused core kernel
+#ifdef LEG_G_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+#else
+    *reinterpret_cast<v2d_t*>(p) = v;
+#endif
+}
 RD void store2_stream(double* p, double a, double b) {
     v2d_t v = {a, b};
 #ifdef RAPTOR_NT_STORES
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             // instead of every block: 1.18 -> 1.22 ms).
             const int tl_u = (ntail > 0) ? tid / ntail : LEG_BLOCK, tl_c = (ntail > 0) ? 2 * (LEG_BLOCK + tid % ntail) - cc : 0;
             auto tail_rows = [&](double* rows, const int count) {  // rows: address of the lane's chunk in the first row of the run
-                if (ntail > 0 && LEG_G_ON(tl_u < count)) *reinterpret_cast<v2d_t*>(rows + (size_t)tl_u * n + tl_c) = zero2;
+                if (ntail > 0 && LEG_G_ON(tl_u < count)) g_st(rows + (size_t)tl_u * n + tl_c, zero2);
             };
             // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
             {
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         for (int u = 0; u < 6; u++) {
                             const double v0 = d0[u][0] * W[sx][0][0] + d1[u][0] * W[sx][1][0] + d2[u][0] * W[sx][2][0];
                             const double v1 = d0[u][NH - 1] * W[sx][0][1] + d1[u][NH - 1] * W[sx][1][1] + d2[u][NH - 1] * W[sx][2][1];
-                            if (LEG_G_ON(lane_on && r0 + u < ni)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * ni + r0 + u) * n) = v2d_t{lv[0] ? v0 : 0.0, lv[1] ? v1 : 0.0};
+                            if (LEG_G_ON(lane_on && r0 + u < ni)) g_st(dst + (size_t)(sx * ni + r0 + u) * n, v2d_t{lv[0] ? v0 : 0.0, lv[1] ? v1 : 0.0});
                         }
                         tail_rows(dst + (size_t)(sx * ni + r0) * n, min(6, ni - r0));
                     }
@@ -1222,13 +1229,13 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
                     for (int u = 0; u < RB; u++) {  // (1.0 * B_k is B_k exactly)
                         const double ma = isind[u] ? one[u][0] : (take[u][0] ? g0[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g0[u][NH - 1] : 0.0);
-                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(j0 + u) * n) = v2d_t{lv[0] ? ma * W[0][0][0] : 0.0, lv[1] ? mb * W[0][0][1] : 0.0};
+                        if (LEG_G_ON(lane_on && u < cnt)) g_st(dst + (size_t)(j0 + u) * n, v2d_t{lv[0] ? ma * W[0][0][0] : 0.0, lv[1] ? mb * W[0][0][1] : 0.0});
                     }
                     tail_rows(dst + (size_t)j0 * n, cnt);
 #pragma unroll
                     for (int u = 0; u < RB; u++) {
                         const double ma = isind[u] ? one[u][0] : (take[u][0] ? g1[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g1[u][NH - 1] : 0.0);
-                        if (LEG_G_ON(lane_on && u < cnt)) *reinterpret_cast<v2d_t*>(dst + (size_t)(nv + j0 + u) * n) = v2d_t{lv[0] ? ma * W[1][0][0] : 0.0, lv[1] ? mb * W[1][0][1] : 0.0};
+                        if (LEG_G_ON(lane_on && u < cnt)) g_st(dst + (size_t)(nv + j0 + u) * n, v2d_t{lv[0] ? ma * W[1][0][0] : 0.0, lv[1] ? mb * W[1][0][1] : 0.0});
                     }
                     tail_rows(dst + (size_t)(nv + j0) * n, cnt);
                 }
@@ -1257,7 +1264,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     for (int rr = 0; rr < 7; rr++) {
                         const double v0 = lv[0] ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
                         const double v1 = lv[1] ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
-                        if (LEG_G_ON(lane_on)) *reinterpret_cast<v2d_t*>(dst + (size_t)(sx * 7 + rr) * n) = v2d_t{v0, v1};
+                        if (LEG_G_ON(lane_on)) g_st(dst + (size_t)(sx * 7 + rr) * n, v2d_t{v0, v1});
                     }
                     tail_rows(dst + (size_t)(sx * 7) * n, 7);
                 }
@@ -1300,12 +1307,12 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const double cfa = ca[w] * da[w][0] + cb[w] * (hasb[w] ? db[w][0] : 0.0);
                         const double cfb = ca[w] * da[w][NH - 1] + cb[w] * (hasb[w] ? db[w][NH - 1] : 0.0);
                         if (LEG_G_ON(lane_on && on[w]))
-                            *reinterpret_cast<v2d_t*>(dst + (size_t)row[w] * n) = v2d_t{lv[0] ? cfa * W[w & 1][0][0] : 0.0, lv[1] ? cfb * W[w & 1][0][1] : 0.0};
+                            g_st(dst + (size_t)row[w] * n, v2d_t{lv[0] ? cfa * W[w & 1][0][0] : 0.0, lv[1] ? cfb * W[w & 1][0][1] : 0.0});
                     }
                     if (ntail > 0) {
                         const int rw = (tl_u == 0) ? row[0] : ((tl_u == 1) ? row[1] : ((tl_u == 2) ? row[2] : row[3]));
                         const bool ok = (tl_u == 0) ? on[0] : ((tl_u == 1) ? on[1] : ((tl_u == 2) ? on[2] : (tl_u == 3 && on[3])));
-                        if (LEG_G_ON(ok)) *reinterpret_cast<v2d_t*>(dst + (size_t)rw * n + tl_c) = zero2;
+                        if (LEG_G_ON(ok)) g_st(dst + (size_t)rw * n + tl_c, zero2);
                     }
                 }
             }
