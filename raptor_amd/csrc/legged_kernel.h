@@ -16,7 +16,7 @@
 // No 6x6 solve, no FK tensors; identical results (numpy model: scripts/proto_rerooted.py agrees with the oracle's
 // literal restatement to 1e-15).
 //
-// Two kernels:
+// Two kernels (since round 3 the first also does the second's work whenever the sizes allow: FUSE instances, phase G):
 //   legged_core_kernel  : LG lanes per sample-eval (lane = body of the re-rooted tree, DFS pre-order so that a subtree
 //                         is a lane range and composites are suffix-scan differences on wave shuffles).  Writes the
 //                         g rows and a compact per-sample record: D_q, D_v, D_a (ni x ni), d lambda (6 x ni x 3), P_dep.
