@@ -119,6 +119,7 @@ struct DevLegged {
     int ind_slot[RAPTOR_LEG_MAX_IND];         // slot of t in those joints' records (0: driver a, 1: driver b)
     int ind_loop_col[RAPTOR_LEG_MAX_IND][2];  // minimal columns of the drivers (a, b) of t's loop, -1: none
     int dep_col[RAPTOR_MAX_NV][2];            // by dependent index (>= 6): minimal columns of its two P_dep entries
+    int dep_body[RAPTOR_MAX_NV];              // by dependent index (>= 6): the body whose joint it is (0 for the floating base)
     // robot-specific "customized" block (swing-foot / torso rows): rows are linear in 12 pose quantities of ONE sample,
     // X[0..5] = swing-foot x y z roll pitch yaw, X[6..11] = floating-base coordinates q[0..5]
     int ncust, off_cust;                      // rows (0: block absent), offset in Optimizer row order

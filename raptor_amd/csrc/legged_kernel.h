@@ -688,6 +688,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                          Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
 #pragma unroll
         for (int k = 0; k < 6; k++) rec[Q->c_lam + k] = lam[k];
+        if (FUSE) {  // phase G reads it from the root body's vector slot, which nothing else uses
+#pragma unroll
+            for (int k = 0; k < 6; k++) sl[LL::V + k] = lam[k];
+        }
         if (G != nullptr) {  // RectangleSurfaceContactConstraints.cpp:35-50
             double* gc = G + rowbase + Q->off_contact + (size_t)i * 7;
             const double ff = sqrt(lam[0] * lam[0] + lam[1] * lam[1]);
@@ -793,6 +797,26 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     LEG_PHASE_END(5, sv_sum(F) + sv_sum(BtS) + tt)
 
 
+    // FUSE: what the column lanes produce stays on chip for phase G -- d(lambda) in registers (read there by shuffles with
+    // constant register indices), the P_dep rows of the floating base and of the swing foot in registers until phase F2 has
+    // finished with its scratch, then in LDS.  Neither the D blocks nor these go through the global record and back.
+    // (PREC, LG = 32: these 30 values per column lane go through the record after all -- kept in registers across phase F2 the Digit
+    // instance spilled 44 of them; they are 720 doubles per wavefront, read back once, against 1764 for the whole records)
+#ifndef LEG_PREC16
+#define LEG_PREC16 0
+#endif
+#ifndef LEG_PREC32
+#define LEG_PREC32 0
+#endif
+    constexpr int PMODE = !FUSE ? 0 : (LG == 32 ? LEG_PREC32 : (LEG_PREC16 ? 2 : 0));  // 0: registers, 1: P rows via the record, 2: L too
+    constexpr bool PREC = PMODE >= 1, LREC = PMODE >= 2;
+    double keepL[FUSE ? 18 : 1], keepP[FUSE ? 12 : 1];
+    if (FUSE) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) keepL[FUSE ? k : 0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) keepP[FUSE ? k : 0] = 0.0;
+    }
     // ---- phase F1: column pass.  Lane t < ni = actuator column t: d(root wrench), torso twist, swing-foot twist per unit
     // (q, v, a) of actuator t, summed over the tree joints that move with it (<= 8).  These are whole-tree quantities with
     // no row structure, so one lane per column is the natural mapping.
@@ -873,21 +897,30 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                                       Q->Ades[1] * np.x + Q->Ades[4] * np.y + Q->Ades[7] * np.z,
                                       Q->Ades[2] * np.x + Q->Ades[5] * np.y + Q->Ades[8] * np.z};
 #pragma unroll
-                for (int r = 0; r < 6; r++) rec[Q->c_L + (x * 6 + r) * ni + t] = lm[r];  // [x][r][it]: the column lanes write runs of 8 * ni bytes
+                for (int r = 0; r < 6; r++) {
+                    if (FUSE && !LREC) keepL[FUSE ? x * 6 + r : 0] = lm[r];
+                    else rec[Q->c_L + (x * 6 + r) * ni + t] = lm[r];  // [x][r][it]: the column lanes write runs of 8 * ni bytes
+                }
             }
             {   // P_dep rows of the floating base (= -J_dep^-1 J_indep, TalosDynamicsConstraints.cpp:243-246)
                 const V3 lin = twt.l + cross(twt.a, ot);
                 const V3 rot = rpy_rates(Rt, twt.a);
                 const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
-                for (int k = 0; k < 6; k++) rec[Q->c_P + k * ni + t] = pc[k];
+                for (int k = 0; k < 6; k++) {
+                    rec[Q->c_P + k * ni + t] = pc[k];  // (the reset-map kernel reads these rows of the last sample)
+                    if (FUSE && !PREC) keepP[FUSE ? k : 0] = pc[k];
+                }
             }
             if (Q->ncust > 0) {  // swing-foot pose derivative (FK Jacobians times pq_pz, DigitCustomizedConstraints.cpp:80-82)
                 const V3 lin = tws.l + cross(tws.a, ps);
                 const V3 rot = rpy_rates(Rs, tws.a);
                 const double pc[6] = {lin.x, lin.y, lin.z, rot.x, rot.y, rot.z};
 #pragma unroll
-                for (int k = 0; k < 6; k++) rec[Q->c_Psf + k * ni + t] = pc[k];
+                for (int k = 0; k < 6; k++) {
+                    if (FUSE && !PREC) keepP[FUSE ? 6 + k : 0] = pc[k];
+                    else rec[Q->c_Psf + k * ni + t] = pc[k];
+                }
             }
         }
     }
@@ -1025,6 +1058,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         for (int set = 0; set < 2; set++) {
             const int it = (int)(set == 0 ? (ent >> 15 & 15u) : (ent >> 19 & 15u));
             if (it == 15) continue;  // uniform
+            // (FUSE) the body whose joint is actuator `it`: the lane of the first lane group that carries trajectory index `it`
+            const int g_it = FUSE ? (int)(__builtin_ctzll(__builtin_amdgcn_ballot_w64(tj == it) | (1ull << 63)) & (LG - 1)) : 0;
             const double Sq = set == 0 ? Tq : Xq, Sv = set == 0 ? Tv : Xv, Sa = set == 0 ? Ta : Xa;
             {   // every lane writes its slot; a lane without a joint writes exact zeros (selected, not 0 * x: a non-finite vector of
                 // some joint must not reach the actuators that read slot 0 for their absent entries)
@@ -1058,8 +1093,15 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 }
                 if (it == (int)(apk >> 3 & 15u)) Rq += Kq[0];
                 if (it == (int)(apk >> 7 & 15u)) Rq += Kq[1];
-                double* D = rec + cD + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
-                D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
+                if (FUSE) {
+                    // column `it` is done with the vectors of the joints it moves: its D block (3 ni <= 36 doubles) takes the slot of
+                    // its own joint (that joint moves with no other column)
+                    double* Dl = sl + LL::V + g_it * LEG_VEC + tj;
+                    Dl[0] = Rq; Dl[ni] = Rv; Dl[2 * ni] = Ra;
+                } else {
+                    double* D = rec + cD + (it * 3) * ni + tj;  // the actuators' lanes write 8 * ni contiguous bytes per store
+                    D[0] = Rq; D[ni] = Rv; D[2 * ni] = Ra;
+                }
             }
             wave_sync();
         }
@@ -1084,34 +1126,63 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     if constexpr (FUSE) {
         constexpr int NH = KEVEN ? 1 : 2;  // distinct actuators a chunk can touch
         constexpr int RB = KEVEN ? 6 : 4;  // rows per block of the joint-limit piece (its per-row state doubles with NH)
-        const int stride = Q->c_stride, K = Q->K, n = L.n;
+        const int K = Q->K, n = L.n;
         const int ndyn = ni * K, cpr = n >> 1;
         const int ntail = cpr - LEG_BLOCK;  // chunks of a row beyond the wavefront's 64 (> 0 for Digit: 66 chunks)
         const int cc = 2 * tid;
         const bool lane_on = tid < cpr;
         bool lv[2];
-        int th[2], kh[2];
+        int th[2], kh[2], bth[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             lv[h] = cc + h < ndyn;
             th[h] = lv[h] ? (cc + h) / K : 0;
             kh[h] = lv[h] ? cc + h - th[h] * K : 0;
+            bth[h] = Q->ind_body[th[h]];  // the body whose vector slot holds the D block of column th (phase F2)
         }
-        const int cD = Q->c_D, cP = Q->c_P, cPl = Q->c_Pl, cL = Q->c_L, clam = Q->c_lam;
         const int off_tau = Q->off_tau, off_q = Q->off_q, off_contact = Q->off_contact;
         const v2d_t zero2 = v2d_t{0.0, 0.0};
-        double* xrec = lds;  // [2][stride]
-        // lane j < nv: what row j of the joint-limit block is (independent column, floating-base row, closed-loop row and its two
-        // driver columns) -- fetched by the lanes in parallel and handed out with v_readlane: three dependent scalar loads per row were
-        // most of this phase's time
-        int ri_info = 0, ri_c0 = -1, ri_c1 = -1;
+        // lane j < nv: what row j of the joint-limit block is (independent column, floating-base row, closed-loop row with its two
+        // driver columns and the body that carries the joint) -- fetched by the lanes in parallel and handed out with v_readlane:
+        // three dependent scalar loads per row were most of this phase's time
+        int ri_info = 0, ri_c0 = -1, ri_c1 = -1, ri_body = 0;
         if (tid < nv) {
             const int ind = Q->joint_ind[tid];
             const int dd = Q->joint_dep[tid];
             ri_info = ind >= 0 ? ind : -1 - dd;
-            if (ind < 0 && dd >= 6) { ri_c0 = Q->dep_col[dd][0]; ri_c1 = Q->dep_col[dd][1]; }
+            if (ind < 0 && dd >= 6) { ri_c0 = Q->dep_col[dd][0]; ri_c1 = Q->dep_col[dd][1]; ri_body = Q->dep_body[dd]; }
         }
-        const int ncust = Q->ncust, off_cust = Q->off_cust, cPsf = Q->c_Psf;
+        const int ncust = Q->ncust, off_cust = Q->off_cust;
+        // Where the twelve P rows (floating base 0..5, swing foot 6..11; ni doubles each) wait in a sample-eval's LDS area once phase F2
+        // is done: its per-joint scratch (LG * TSS doubles), then the vector slots of the lanes without a body (nb .. LG - 1), three rows
+        // per slot.  The actuators' slots hold the D blocks, the root body's slot lambda.  (Host: the rows fit, legged_can_fuse.)
+        const int nts = (LG * LL::TSS) / ni;
+        auto prow = [&](const int k) {  // (uniform)
+            const int r = k - nts;
+            const int s3 = (r >= 6) ? 2 : ((r >= 3) ? 1 : 0);
+            return (k < nts) ? LL::TS + k * ni : LL::V + (nb + s3) * LEG_VEC + (r - 3 * s3) * ni;
+        };
+        wave_sync();  // phase F2's last reads of its scratch
+        {
+            const int t_ = (LG == 32) ? (g & 15) : g;
+            if (t_ < ni && (LG != 32 || g < 16)) {  // the column lanes of phase F1
+                double pk[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) pk[k] = PREC ? rec[((k < 6) ? Q->c_P + k * ni : Q->c_Psf + (k - 6) * ni) + t_] : keepP[PREC ? 0 : k];
+#pragma unroll
+                for (int k = 0; k < 12; k++) sl[prow(k) + t_] = pk[k];
+            }
+        }
+        wave_sync();
+        auto bcast = [&](const double x, const int l) {
+            const long long xi = __double_as_longlong(x);
+            return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(xi >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xi, l));
+        };
+        auto shfl64 = [&](const double x, const int l) {  // any lane of the wavefront
+            const long long xi = __double_as_longlong(x);
+            const int lo = __builtin_amdgcn_ds_bpermute(l << 2, (int)(xi & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(l << 2, (int)(xi >> 32));
+            return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        };
 #pragma unroll 1
         for (int rd = 0; rd < EPB / 2; rd++) {
             const long long ea = e0 + 2 * rd;
@@ -1119,9 +1190,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             int ia = (int)(e0 - b0 * N) + 2 * rd;
             long long ba = b0;
             while (ia >= N) { ia -= N; ba++; }
-            wave_sync();  // the record stores above and the loads below are one wavefront's vector-memory operations: performed in order
             // customized rows of these two samples: lane g of lane group 2 rd + sx holds the g-th row of sample ia + sx
             const int l0 = 2 * rd * LG;  // first lane of the pair's two lane groups
+            const double* sa[2] = {lds + (2 * rd) * LL::STRIDE, lds + (2 * rd + 1) * LL::STRIDE};  // the two sample-evals' LDS areas
             int cu_row = 0, cu_qa = 0, cu_qb = -1, cu_n = 0;
             double cu_ca = 0.0, cu_cb = 0.0;
             if (ncust > 0 && (eg >> 1) == rd) {
@@ -1143,24 +1214,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const double w = basis[(size_t)((ia + sx) * 3 + o) * K + kh[h]];
                         W[sx][o][h] = lv[h] ? w : 0.0;
                     }
-            {   // the two records back from L2, 16 bytes per lane and seven loads in flight (one load per trip of a plain loop is a chain of
-                // ~28 L2 round trips: 0.16 ms of the launch)
-                const v2d_t* src2 = reinterpret_cast<const v2d_t*>(core + (size_t)ea * stride);
-                v2d_t* dst2 = reinterpret_cast<v2d_t*>(xrec);
-                const int nch = stride;  // 2 * stride doubles
-#pragma unroll 1
-                for (int k0 = 0; k0 < nch; k0 += 7 * LEG_BLOCK) {
-                    v2d_t buf[7];
-#pragma unroll
-                    for (int u = 0; u < 7; u++) buf[u] = src2[min(k0 + u * LEG_BLOCK + tid, nch - 1)];
-#pragma unroll
-                    for (int u = 0; u < 7; u++)
-                        if (k0 + u * LEG_BLOCK + tid < nch) dst2[k0 + u * LEG_BLOCK + tid] = buf[u];
-                }
-            }
-            wave_sync();
-#if defined(LEG_G_PROBE) && LEG_G_PROBE == 2  // measurement build: the readback alone
-            if (tid == 0) JAC[(size_t)ea] = xrec[tid] + xrec[stride + 5] + W[0][0][0] + W[1][2][1];
+#if defined(LEG_G_PROBE) && LEG_G_PROBE == 2  // measurement build: the phase's set-up alone
+            if (tid == 0) JAC[(size_t)ea] = sa[0][tid] + sa[1][5] + W[0][0][0] + W[1][2][1];
             continue;
 #endif
             double* base = JAC + (size_t)ba * L.m * n + cc;
@@ -1174,12 +1229,12 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             auto tail_rows = [&](double* rows, const int count) {  // rows: address of the lane's chunk in the first row of the run
                 if (ntail > 0 && LEG_G_ON(tl_u < count)) g_st(rows + (size_t)tl_u * n + tl_c, zero2);
             };
-            // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz
+            // -- TorqueLimits.cpp:36-40 on ConstrainedInverseDynamics::ptau_pz: D[x][row] of column t from the slot of t's own joint
             {
                 double* dst = base + ((size_t)off_tau + (size_t)ia * ni) * n;
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
-                    const double* dh[2] = {xrec + sx * stride + cD + (th[0] * 3) * ni, xrec + sx * stride + cD + (th[1] * 3) * ni};
+                    const double* dh[2] = {sa[sx] + LL::V + bth[0] * LEG_VEC, sa[sx] + LL::V + bth[1] * LEG_VEC};
 #pragma unroll 1
                     for (int r0 = 0; r0 < ni; r0 += 6) {
                         double d0[6][NH], d1[6][NH], d2[6][NH];
@@ -1200,47 +1255,50 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 }
             }
             // -- ConstrainedJointLimits.cpp:59-68: row j is B_k at the joint's own column (independent joint) or P_dep(j, t) B_k
+            // (floating-base rows: the P rows parked in LDS; closed-loop rows: Y1 of the joint, still in the registers of its body's lane)
             {
                 double* dst = base + ((size_t)off_q + (size_t)ia * nv) * n;
 #pragma unroll 1
                 for (int j0 = 0; j0 < nv; j0 += RB) {
-                    double g0[RB][NH], g1[RB][NH], one[RB][NH];
-                    bool isind[RB], take[RB][NH];
+                    double gg[2][RB][NH];
+                    bool isind[RB];
 #pragma unroll
                     for (int u = 0; u < RB; u++) {
                         const int j = min(j0 + u, nv - 1);
                         const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
                         const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
+                        const int bj = __builtin_amdgcn_readlane(ri_body, j);
                         const int dd = -1 - info;
                         isind[u] = info >= 0;
-                        const bool isbase = dd < 6;
-                        // one unconditional read per sample from an address every lane may read: an independent row reads entry 0 and drops it
-                        const int offu = isind[u] ? 0 : (isbase ? cP + dd * ni : cPl + (dd - 6) * 2);
+                        const bool isbase = !isind[u] && dd < 6;
+                        const int offu = isbase ? prow(dd) : LL::V;  // (an address every lane may read; dropped unless a floating-base row)
 #pragma unroll
-                        for (int h = 0; h < NH; h++) {
-                            const int offl = isind[u] ? 0 : (isbase ? th[h] : ((th[h] == c0) ? 0 : 1));
-                            take[u][h] = isbase || th[h] == c0 || th[h] == c1;
-                            one[u][h] = (info == th[h]) ? 1.0 : 0.0;  // (a dead column's weight is zero)
-                            g0[u][h] = xrec[offu + offl];
-                            g1[u][h] = xrec[stride + offu + offl];
+                        for (int sx = 0; sx < 2; sx++) {
+                            const double p0 = bcast(w0[0], l0 + sx * LG + bj), p1 = bcast(w1[0], l0 + sx * LG + bj);
+#pragma unroll
+                            for (int h = 0; h < NH; h++) {
+                                const double pb = sa[sx][offu + (isbase ? th[h] : 0)];
+                                const double pl = (th[h] == c0) ? p0 : ((th[h] == c1) ? p1 : 0.0);
+                                const double one = (info == th[h]) ? 1.0 : 0.0;  // (1.0 * B_k is B_k exactly; a dead column's weight is zero)
+                                gg[sx][u][h] = isind[u] ? one : (isbase ? pb : pl);
+                            }
                         }
                     }
                     const int cnt = min(RB, nv - j0);
 #pragma unroll
-                    for (int u = 0; u < RB; u++) {  // (1.0 * B_k is B_k exactly)
-                        const double ma = isind[u] ? one[u][0] : (take[u][0] ? g0[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g0[u][NH - 1] : 0.0);
-                        if (LEG_G_ON(lane_on && u < cnt)) g_st(dst + (size_t)(j0 + u) * n, v2d_t{lv[0] ? ma * W[0][0][0] : 0.0, lv[1] ? mb * W[0][0][1] : 0.0});
-                    }
-                    tail_rows(dst + (size_t)j0 * n, cnt);
+                    for (int sx = 0; sx < 2; sx++) {
 #pragma unroll
-                    for (int u = 0; u < RB; u++) {
-                        const double ma = isind[u] ? one[u][0] : (take[u][0] ? g1[u][0] : 0.0), mb = isind[u] ? one[u][NH - 1] : (take[u][NH - 1] ? g1[u][NH - 1] : 0.0);
-                        if (LEG_G_ON(lane_on && u < cnt)) g_st(dst + (size_t)(nv + j0 + u) * n, v2d_t{lv[0] ? ma * W[1][0][0] : 0.0, lv[1] ? mb * W[1][0][1] : 0.0});
+                        for (int u = 0; u < RB; u++) {
+                            const double ma = gg[sx][u][0], mb = gg[sx][u][NH - 1];
+                            if (LEG_G_ON(lane_on && u < cnt))
+                                g_st(dst + (size_t)(sx * nv + j0 + u) * n, v2d_t{lv[0] ? ma * W[sx][0][0] : 0.0, lv[1] ? mb * W[sx][0][1] : 0.0});
+                        }
+                        tail_rows(dst + (size_t)(sx * nv + j0) * n, cnt);
                     }
-                    tail_rows(dst + (size_t)(nv + j0) * n, cnt);
                 }
             }
-            // -- RectangleSurfaceContactConstraints.cpp:52-93
+            // -- RectangleSurfaceContactConstraints.cpp:52-93: d(lambda.tail(6)) per unit (q, v, a) of actuator t from the registers
+            // of t's column lane (phase F1), lambda from the root body's slot
             {
                 double* dst = base + ((size_t)off_contact + (size_t)ia * 7) * n;
                 double p[2][2][6];
@@ -1250,16 +1308,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     for (int q6 = 0; q6 < 6; q6++) {
                         double lq[3][NH];
 #pragma unroll
-                        for (int h = 0; h < NH; h++) {
-                            const double* l = xrec + sx * stride + cL + th[h];
-                            lq[0][h] = l[q6 * ni]; lq[1][h] = l[(6 + q6) * ni]; lq[2][h] = l[(12 + q6) * ni];
-                        }
+                        for (int h = 0; h < NH; h++)
+#pragma unroll
+                            for (int x = 0; x < 3; x++)
+                                lq[x][h] = LREC ? core[(size_t)(ea + sx) * Q->c_stride + Q->c_L + (x * 6 + q6) * ni + th[h]]
+                                                : shfl64(keepL[LREC ? 0 : x * 6 + q6], l0 + sx * LG + th[h]);
                         p[sx][0][q6] = lq[0][0] * W[sx][0][0] + lq[1][0] * W[sx][1][0] + lq[2][0] * W[sx][2][0];
                         p[sx][1][q6] = lq[0][NH - 1] * W[sx][0][1] + lq[1][NH - 1] * W[sx][1][1] + lq[2][NH - 1] * W[sx][2][1];
                     }
 #pragma unroll
                 for (int sx = 0; sx < 2; sx++) {
-                    const double* lam = xrec + sx * stride + clam;
+                    const double* lam = sa[sx] + LL::V;
 #pragma unroll
                     for (int rr = 0; rr < 7; rr++) {
                         const double v0 = lv[0] ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
@@ -1274,10 +1333,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
             // quantity-major -- two quantities x two samples per block, each pair of adjacent rows stored back to back.
             if (ncust > 0) {
                 double* dst = base + (size_t)off_cust * n;
-                auto bcast = [&](const double x, const int l) {
-                    const long long xi = __double_as_longlong(x);
-                    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(xi >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xi, l));
-                };
                 const int n0 = __builtin_amdgcn_readlane(cu_n, l0), n1 = __builtin_amdgcn_readlane(cu_n, l0 + LG);
 #pragma unroll 1
                 for (int r0 = 0; r0 < max(n0, n1); r0 += 2) {
@@ -1295,11 +1350,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         cb[w] = bcast(cu_cb, sl_);
                         hasb[w] = qb >= 0;
                         const int qbb = hasb[w] ? qb : 0;
-                        const double* rs = xrec + sx * stride;
+                        const int oa = prow((qa < 6) ? 6 + qa : qa - 6), ob = prow((qbb < 6) ? 6 + qbb : qbb - 6);  // X[0..5]: swing foot, X[6..11]: base
 #pragma unroll
                         for (int h = 0; h < NH; h++) {
-                            da[w][h] = rs[((qa < 6) ? cPsf + qa * ni : cP + (qa - 6) * ni) + th[h]];
-                            db[w][h] = rs[((qbb < 6) ? cPsf + qbb * ni : cP + (qbb - 6) * ni) + th[h]];
+                            da[w][h] = sa[sx][oa + th[h]];
+                            db[w][h] = sa[sx][ob + th[h]];
                         }
                     }
 #pragma unroll

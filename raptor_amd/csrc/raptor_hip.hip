@@ -693,8 +693,10 @@ bool legged_can_fuse(const raptor_problem& p, const double* dJ) {
     const int LG = p.hleg.nb > 16 ? 32 : 16;
     if (no_fuse || p.htraj.N % 2 != 0 || p.layout.n % 2 != 0 || ((size_t)dJ & 15) != 0) return false;
     if (ndyn > 2 * LEG_BLOCK || p.layout.n > 4 * LEG_BLOCK || p.layout.n < ndyn || p.cust_max_per_sample > LG) return false;
-    const size_t area = (size_t)(LEG_BLOCK / LG) * (LG == 32 ? LegLds<32>::STRIDE : LegLds<16>::STRIDE);  // doubles per wavefront
-    return (size_t)2 * p.hleg.c_stride <= area;
+    // phase G finds the D blocks in the vector slots of the actuators' joints (3 ni <= 36 doubles) and parks twelve P rows in a
+    // sample-eval's scratch and in the slots of the lanes without a body, three rows per slot
+    const int ni = p.hleg.ni, nts = (LG * 4) / std::max(ni, 1);
+    return ni <= 12 && nts >= 3 && nts + 3 * (LG - p.hleg.nb) >= 12;
 }
 
 // wavefronts of the fused core kernel resident at once on the current device (8 one-wavefront workgroups per CU: LDS and registers)
@@ -1689,8 +1691,10 @@ static void legged_setup(raptor_problem& pr, const raptor_model* model, const Le
     Q.c_stride = (off + 1) & ~1;
     for (int dd = 6; dd < nd; dd++) {
         Q.dep_col[dd][0] = Q.dep_col[dd][1] = -1;
+        Q.dep_body[dd] = 0;
         for (int g = 1; g < nb; g++)
             if (Q.body_joint[g] == Q.dep_joint[dd]) {
+                Q.dep_body[dd] = g;
                 Q.dep_col[dd][0] = Q.body_col[g][0];
                 Q.dep_col[dd][1] = Q.body_col[g][1];
             }
