@@ -1125,7 +1125,6 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // LG customized rows.  Pairs of sample-evals are expanded one after the other (LG = 16: two pairs per wavefront).
     if constexpr (FUSE) {
         constexpr int NH = KEVEN ? 1 : 2;  // distinct actuators a chunk can touch
-        constexpr int RB = KEVEN ? 6 : 4;  // rows per block of the joint-limit piece (its per-row state doubles with NH)
         const int K = Q->K, n = L.n;
         const int ndyn = ni * K, cpr = n >> 1;
         const int ntail = cpr - LEG_BLOCK;  // chunks of a row beyond the wavefront's 64 (> 0 for Digit: 66 chunks)
@@ -1255,45 +1254,50 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                 }
             }
             // -- ConstrainedJointLimits.cpp:59-68: row j is B_k at the joint's own column (independent joint) or P_dep(j, t) B_k
-            // (floating-base rows: the P rows parked in LDS; closed-loop rows: Y1 of the joint, still in the registers of its body's lane)
+            // (floating-base rows: the P rows parked in LDS; closed-loop rows: Y1 of the joint, still in the registers of its body's lane).
+            // The kind of a row is uniform: one scalar branch per row, and the commonest kind -- an independent joint -- touches neither
+            // LDS nor another lane (as one branch-free block of rows every row paid for all three kinds: 60 instructions a row).
             {
                 double* dst = base + ((size_t)off_q + (size_t)ia * nv) * n;
 #pragma unroll 1
-                for (int j0 = 0; j0 < nv; j0 += RB) {
-                    double gg[2][RB][NH];
-                    bool isind[RB];
+                for (int j = 0; j < nv; j++) {
+                    const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
+                    double m[2][2];
+                    if (info >= 0) {
 #pragma unroll
-                    for (int u = 0; u < RB; u++) {
-                        const int j = min(j0 + u, nv - 1);
-                        const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
+                        for (int sx = 0; sx < 2; sx++)
+#pragma unroll
+                            for (int h = 0; h < 2; h++) m[sx][h] = (info == th[h]) ? W[sx][0][h] : 0.0;  // (a dead column's weight is zero)
+                    } else if (info >= -6) {
+                        const int off = prow(-1 - info);
+#pragma unroll
+                        for (int sx = 0; sx < 2; sx++) {
+                            double pb[NH];
+#pragma unroll
+                            for (int h = 0; h < NH; h++) pb[h] = sa[sx][off + th[h]];
+                            m[sx][0] = lv[0] ? pb[0] * W[sx][0][0] : 0.0;
+                            m[sx][1] = lv[1] ? pb[NH - 1] * W[sx][0][1] : 0.0;
+                        }
+                    } else {
                         const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
                         const int bj = __builtin_amdgcn_readlane(ri_body, j);
-                        const int dd = -1 - info;
-                        isind[u] = info >= 0;
-                        const bool isbase = !isind[u] && dd < 6;
-                        const int offu = isbase ? prow(dd) : LL::V;  // (an address every lane may read; dropped unless a floating-base row)
 #pragma unroll
                         for (int sx = 0; sx < 2; sx++) {
                             const double p0 = bcast(w0[0], l0 + sx * LG + bj), p1 = bcast(w1[0], l0 + sx * LG + bj);
 #pragma unroll
-                            for (int h = 0; h < NH; h++) {
-                                const double pb = sa[sx][offu + (isbase ? th[h] : 0)];
+                            for (int h = 0; h < 2; h++) {
                                 const double pl = (th[h] == c0) ? p0 : ((th[h] == c1) ? p1 : 0.0);
-                                const double one = (info == th[h]) ? 1.0 : 0.0;  // (1.0 * B_k is B_k exactly; a dead column's weight is zero)
-                                gg[sx][u][h] = isind[u] ? one : (isbase ? pb : pl);
+                                m[sx][h] = lv[h] ? pl * W[sx][0][h] : 0.0;
                             }
                         }
                     }
-                    const int cnt = min(RB, nv - j0);
 #pragma unroll
-                    for (int sx = 0; sx < 2; sx++) {
-#pragma unroll
-                        for (int u = 0; u < RB; u++) {
-                            const double ma = gg[sx][u][0], mb = gg[sx][u][NH - 1];
-                            if (LEG_G_ON(lane_on && u < cnt))
-                                g_st(dst + (size_t)(sx * nv + j0 + u) * n, v2d_t{lv[0] ? ma * W[sx][0][0] : 0.0, lv[1] ? mb * W[sx][0][1] : 0.0});
-                        }
-                        tail_rows(dst + (size_t)(sx * nv + j0) * n, cnt);
+                    for (int sx = 0; sx < 2; sx++)
+                        if (LEG_G_ON(lane_on)) g_st(dst + (size_t)(sx * nv + j) * n, v2d_t{m[sx][0], m[sx][1]});
+                    if (j % 6 == 5 || j == nv - 1) {  // the tail chunks of the last (up to) six rows, both samples
+                        const int j0 = j - j % 6;
+                        tail_rows(dst + (size_t)j0 * n, j - j0 + 1);
+                        tail_rows(dst + (size_t)(nv + j0) * n, j - j0 + 1);
                     }
                 }
             }
