@@ -604,6 +604,11 @@ def test_legged_fused_rows_against_two_kernel_form(oracle, hip, which, N, B, mon
         check(out[form][1], Jo)
         check_blocks(out[form][0], out[form][1], Go, Jo, po)
     monkeypatch.delenv("RAPTOR_NO_FUSE", raising=False)
+    # eval_jac_g alone (no G buffer): the same Jacobian, bit for bit
+    J = torch.full((B, ph.m, ph.n), float("nan"), dtype=torch.float64, device="cuda")
+    ph.eval_device(Zd.data_ptr(), B, A.EVAL_JAC, 0, J.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(J.cpu().numpy(), out["fused"][1])
     assert np.array_equal(out["fused"][0], out["two_kernel"][0])
     Jf, Jt = out["fused"][1], out["two_kernel"][1]
     assert np.array_equal(Jf == 0.0, Jt == 0.0)  # the same structural zeros
