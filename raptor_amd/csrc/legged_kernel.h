@@ -35,7 +35,7 @@
 #endif
 #define LEG_VEC 36        // per-joint 6-vectors kept in LDS: s, sd, psi, IS, cv, cq
 #ifndef LEG_STAGGER
-#define LEG_STAGGER 4     // fused core kernel: start offset between the hardware slots of a CU, in s_sleep(127) units (measured 2 / 4 / 8 / 16)
+#define LEG_STAGGER 2     // fused core kernel: start offset between the hardware slots of a CU, in s_sleep(127) units of ~3.5 us (measured 0 .. 32)
 #endif
 // Measurement builds of the fused core kernel's phase G: -DLEG_G_PROBE=1 drops its stores (one lane in 2^20 keeps the
 // values alive), =2 ends the phase after the records are back in LDS.
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
     const double* __restrict__ loops, const DevCustRow* __restrict__ cust, const int* __restrict__ cust_list,
     const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec,
-    double* __restrict__ JAC = nullptr, const int stagger_wgs = 0) {
+    double* __restrict__ JAC = nullptr, const int stagger_wgs = 0, const int stagger_units = LEG_STAGGER) {
     // lamrec (may be null; the component view raptor_constrained_id_lambda_host only): per sample-eval the tree torque of every
     // closed-loop joint and its derivative per unit (q, v, a) of every actuator,  tau[nrec] | T[it][x][nrec]
     extern __shared__ __align__(16) double lds[];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         const unsigned simd = __builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4);  // HW_REG_HW_ID: wave_id [3:0], simd_id [5:4]
         const unsigned wslot = __builtin_amdgcn_s_getreg((1 - 1) << 11 | 0 << 6 | 4);
         const int slot = (int)(wslot * 4u + simd);
-        for (int k = 0; k < slot * LEG_STAGGER; k++) __builtin_amdgcn_s_sleep(127);  // 127 * 64 clocks ~ 3.5 us each
+        for (int k = 0; k < slot * stagger_units; k++) __builtin_amdgcn_s_sleep(127);  // 127 * 64 clocks ~ 3.5 us each
     }
     const int g = tid & (LG - 1);
     const int eg = tid / LG;

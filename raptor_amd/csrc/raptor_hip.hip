@@ -741,12 +741,17 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
 #define LEG_LAUNCH_FUSED(LGV, KE)                                                                                            \
     hipLaunchKernelGGL((legged_core_kernel<LGV, true, true, KE>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,       \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,                 \
-                       p.d_cust_start.p, dG, p.s_core.p, d_lamrec, dJ_fused, stagger)
+                       p.d_cust_start.p, dG, p.s_core.p, d_lamrec, dJ_fused, stagger, stagger_units)
     if (deriv && dJ_fused != nullptr) {
         const bool keven = p.hleg.K % 2 == 0;
-        // the staggered start (up to ~0.1 ms for the last slot) pays once the launch has a steady state: at least four rounds of wavefronts
+        // the staggered start (slot k of a CU waits k x units x 3.5 us) pays once the launch is more than one round of wavefronts
+        // (measured, units 0 / 1 / 2 / 3 at 1.75 rounds: G1 1024 problems 0.218 / 0.214 / 0.207 / 0.223 ms, Digit 1024 problems
+        // 0.354 / 0.348 / 0.330 / 0.330 ms; at 14 rounds 2 and 4 are equal); a single problem must not wait at all
+        static const int units_env = std::getenv("RAPTOR_STAGGER_UNITS") ? std::atoi(std::getenv("RAPTOR_STAGGER_UNITS")) : -1;  // experiments
         const int first = fused_first_round();
-        const int stagger = ((long long)grid >= 4LL * first) ? first : 0;
+        const bool rounds = 2LL * grid >= 3LL * first;
+        const int stagger = rounds ? first : 0;
+        const int stagger_units = units_env >= 0 ? units_env : LEG_STAGGER;
         if (wide) { if (keven) LEG_LAUNCH_FUSED(32, true); else LEG_LAUNCH_FUSED(32, false); }
         else { if (keven) LEG_LAUNCH_FUSED(16, true); else LEG_LAUNCH_FUSED(16, false); }
 #undef LEG_LAUNCH_FUSED
