@@ -173,7 +173,7 @@ def parse_args():
     ap.add_argument("--workload", default="kinova", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the Digit record appended to the default (Kinova) line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Digit and Talos records appended to the default (Kinova) line")
     ap.add_argument("--no-multistart", action="store_true", help="skip the G1 multi-start sweep record (configs[4])")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-problem latency loops (profiling runs: keeps the kernel statistics to the batch launches)")
     ap.add_argument("--no-eval-h", action="store_true", help="skip the eval_h record of the Kinova line")
@@ -587,6 +587,9 @@ def run_rank(args) -> None:
         out["secondary"] = {"digit": {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "roofline_fp64", "kernels_ms",
                                                           "single_problem_eval_jac_g_latency_ms", "single_problem_eval_jac_g_latency_ms_host",
                                                           "cpu_baseline") if k in sec}}
+        # BASELINE.json configs[2] (Talos): the same kernels as G1 on the other 18-DoF robot, recorded so that every config has a line
+        sec = run(WORKLOADS["talos"](), 0, 0.0)
+        out["secondary"]["talos"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels_ms") if k in sec}
     if args.workload == "kinova" and not args.no_multistart:
         if world == 1:
             # ONE rank: the RCCL leg of the multi-start record still runs (a one-rank group), so that the exchange step is executed code
