@@ -734,12 +734,14 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const int epb = LEG_BLOCK / LG;
     const size_t lds_bytes = (size_t)epb * (wide ? LegLds<32>::STRIDE : LegLds<16>::STRIDE) * sizeof(double);
     const unsigned grid = (unsigned)((E + epb - 1) / epb);
+    static const size_t lds_extra = std::getenv("RAPTOR_LEG_LDS_EXTRA") ? (size_t)std::atoll(std::getenv("RAPTOR_LEG_LDS_EXTRA")) : 0;  // experiments: fewer wavefronts per CU
+    const size_t lds_fused = lds_bytes + lds_extra;
 #define LEG_LAUNCH(LGV, DV)                                                                                          \
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
                        p.d_cust_start.p, dG, p.s_core.p, d_lamrec)
 #define LEG_LAUNCH_FUSED(LGV, KE)                                                                                            \
-    hipLaunchKernelGGL((legged_core_kernel<LGV, true, true, KE>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,       \
+    hipLaunchKernelGGL((legged_core_kernel<LGV, true, true, KE>), dim3(grid), dim3(LEG_BLOCK), lds_fused, st, p.d_model.p,       \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,                 \
                        p.d_cust_start.p, dG, p.s_core.p, d_lamrec, dJ_fused, stagger, stagger_units)
     if (deriv && dJ_fused != nullptr) {
