@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const double w = basis[(size_t)((ia + sx) * 3 + o) * K + kh[h]];
-                        W[sx][o][h] = lv[h] ? w : 0.0;
+                        W[sx][o][h] = lv[h] ? w : 0.0;  // the structural zeros beyond ni K columns are products with this zero (finite entries: exact)
                     }
 #if defined(LEG_G_PROBE) && LEG_G_PROBE == 2  // measurement build: the phase's set-up alone
             if (tid == 0) JAC[(size_t)ea] = sa[0][tid] + sa[1][5] + W[0][0][0] + W[1][2][1];
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         for (int u = 0; u < 6; u++) {
                             const double v0 = d0[u][0] * W[sx][0][0] + d1[u][0] * W[sx][1][0] + d2[u][0] * W[sx][2][0];
                             const double v1 = d0[u][NH - 1] * W[sx][0][1] + d1[u][NH - 1] * W[sx][1][1] + d2[u][NH - 1] * W[sx][2][1];
-                            if (LEG_G_ON(lane_on && r0 + u < ni)) g_st(dst + (size_t)(sx * ni + r0 + u) * n, v2d_t{lv[0] ? v0 : 0.0, lv[1] ? v1 : 0.0});
+                            if (LEG_G_ON(lane_on && r0 + u < ni)) g_st(dst + (size_t)(sx * ni + r0 + u) * n, v2d_t{v0, v1});
                         }
                         tail_rows(dst + (size_t)(sx * ni + r0) * n, min(6, ni - r0));
                     }
@@ -1264,10 +1264,14 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     const int info = __builtin_amdgcn_readlane(ri_info, j);  // (uniform)
                     double m[2][2];
                     if (info >= 0) {
+                        bool me[NH];
 #pragma unroll
-                        for (int sx = 0; sx < 2; sx++)
+                        for (int h = 0; h < NH; h++) me[h] = info == th[h];
 #pragma unroll
-                            for (int h = 0; h < 2; h++) m[sx][h] = (info == th[h]) ? W[sx][0][h] : 0.0;  // (a dead column's weight is zero)
+                        for (int sx = 0; sx < 2; sx++) {  // (a dead column's weight is zero)
+                            m[sx][0] = me[0] ? W[sx][0][0] : 0.0;
+                            m[sx][1] = me[NH - 1] ? W[sx][0][1] : 0.0;
+                        }
                     } else if (info >= -6) {
                         const int off = prow(-1 - info);
 #pragma unroll
@@ -1275,8 +1279,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                             double pb[NH];
 #pragma unroll
                             for (int h = 0; h < NH; h++) pb[h] = sa[sx][off + th[h]];
-                            m[sx][0] = lv[0] ? pb[0] * W[sx][0][0] : 0.0;
-                            m[sx][1] = lv[1] ? pb[NH - 1] * W[sx][0][1] : 0.0;
+                            m[sx][0] = pb[0] * W[sx][0][0];
+                            m[sx][1] = pb[NH - 1] * W[sx][0][1];
                         }
                     } else {
                         const int c0 = __builtin_amdgcn_readlane(ri_c0, j), c1 = __builtin_amdgcn_readlane(ri_c1, j);
@@ -1284,11 +1288,11 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll
                         for (int sx = 0; sx < 2; sx++) {
                             const double p0 = bcast(w0[0], l0 + sx * LG + bj), p1 = bcast(w1[0], l0 + sx * LG + bj);
+                            double pl[NH];
 #pragma unroll
-                            for (int h = 0; h < 2; h++) {
-                                const double pl = (th[h] == c0) ? p0 : ((th[h] == c1) ? p1 : 0.0);
-                                m[sx][h] = lv[h] ? pl * W[sx][0][h] : 0.0;
-                            }
+                            for (int h = 0; h < NH; h++) pl[h] = (th[h] == c0) ? p0 : ((th[h] == c1) ? p1 : 0.0);
+                            m[sx][0] = pl[0] * W[sx][0][0];
+                            m[sx][1] = pl[NH - 1] * W[sx][0][1];
                         }
                     }
 #pragma unroll
@@ -1325,8 +1329,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     const double* lam = sa[sx] + LL::V;
 #pragma unroll
                     for (int rr = 0; rr < 7; rr++) {
-                        const double v0 = lv[0] ? contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly) : 0.0;
-                        const double v1 = lv[1] ? contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly) : 0.0;
+                        const double v0 = contact_row(rr, lam, p[sx][0], mu, gam, Lx, Ly);
+                        const double v1 = contact_row(rr, lam, p[sx][1], mu, gam, Lx, Ly);
                         if (LEG_G_ON(lane_on)) g_st(dst + (size_t)(sx * 7 + rr) * n, v2d_t{v0, v1});
                     }
                     tail_rows(dst + (size_t)(sx * 7) * n, 7);
@@ -1366,7 +1370,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const double cfa = ca[w] * da[w][0] + cb[w] * (hasb[w] ? db[w][0] : 0.0);
                         const double cfb = ca[w] * da[w][NH - 1] + cb[w] * (hasb[w] ? db[w][NH - 1] : 0.0);
                         if (LEG_G_ON(lane_on && on[w]))
-                            g_st(dst + (size_t)row[w] * n, v2d_t{lv[0] ? cfa * W[w & 1][0][0] : 0.0, lv[1] ? cfb * W[w & 1][0][1] : 0.0});
+                            g_st(dst + (size_t)row[w] * n, v2d_t{cfa * W[w & 1][0][0], cfb * W[w & 1][0][1]});
                     }
                     if (ntail > 0) {
                         const int rw = (tl_u == 0) ? row[0] : ((tl_u == 1) ? row[1] : ((tl_u == 2) ? row[2] : row[3]));
