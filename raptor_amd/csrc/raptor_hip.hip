@@ -735,7 +735,12 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
     const size_t lds_bytes = (size_t)epb * (wide ? LegLds<32>::STRIDE : LegLds<16>::STRIDE) * sizeof(double);
     const unsigned grid = (unsigned)((E + epb - 1) / epb);
     static const size_t lds_extra = std::getenv("RAPTOR_LEG_LDS_EXTRA") ? (size_t)std::atoll(std::getenv("RAPTOR_LEG_LDS_EXTRA")) : 0;  // experiments: fewer wavefronts per CU
-    const size_t lds_fused = lds_bytes + lds_extra;
+    // Talos / G1 (LG = 16), fused form, launches of six rounds of wavefronts or more: SEVEN workgroups per CU instead of eight (the
+    // extra LDS request does it).  Measured, G1, 8 / 7 / 6 per CU: 8192 problems 1.345 / 1.220 / 1.405 ms, 4096 problems 0.686 / 0.649 /
+    // 0.737, 2048 problems 0.367 / 0.365 / 0.404, 1024 problems 0.202 / 0.220 / 0.238 -- the staggered start changes nothing for this
+    // instance, an odd wavefront count per CU (one SIMD runs a single wavefront, at its own pace) does.  Digit (LG = 32) loses 22 % at seven.
+    const bool seven = !wide && (long long)grid >= 6LL * fused_first_round();
+    const size_t lds_fused = lds_bytes + lds_extra + ((seven && lds_extra == 0) ? 2900 : 0);
 #define LEG_LAUNCH(LGV, DV)                                                                                          \
     hipLaunchKernelGGL((legged_core_kernel<LGV, DV>), dim3(grid), dim3(LEG_BLOCK), lds_bytes, st, p.d_model.p,        \
                        p.d_traj.p, p.d_leg.p, p.d_basis.p, p.layout, dZ, E, d_loops, p.d_cust.p, p.d_cust_list.p,      \
