@@ -250,7 +250,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const double* __restrict__ basis, const DevLayout L, const double* __restrict__ Z, const long long E,
     const double* __restrict__ loops, const DevCustRow* __restrict__ cust, const int* __restrict__ cust_list,
     const int* __restrict__ cust_start, double* __restrict__ G, double* __restrict__ core, double* __restrict__ lamrec,
-    double* __restrict__ JAC = nullptr, const int stagger_wgs = 0, const int stagger_units = LEG_STAGGER) {
+    double* __restrict__ JAC = nullptr, const int stagger_wgs = 0, const int stagger_units = (4 * LEG_STAGGER) << 8 | LEG_STAGGER) {
     // lamrec (may be null; the component view raptor_constrained_id_lambda_host only): per sample-eval the tree torque of every
     // closed-loop joint and its derivative per unit (q, v, a) of every actuator,  tau[nrec] | T[it][x][nrec]
     extern __shared__ __align__(16) double lds[];
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
         // their hardware slot (SIMD, wave slot parity); later rounds inherit the offsets because every wavefront does the same work.
         const unsigned simd = __builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4);  // HW_REG_HW_ID: wave_id [3:0], simd_id [5:4]
         const unsigned wslot = __builtin_amdgcn_s_getreg((1 - 1) << 11 | 0 << 6 | 4);
-        const int slot = (int)(wslot * 4u + simd);
-        for (int k = 0; k < slot * stagger_units; k++) __builtin_amdgcn_s_sleep(127);  // 127 * 64 clocks ~ 3.5 us each
+        // stagger_units = (units per wave slot) << 8 | (units per SIMD)
+        const int delay = (int)wslot * (stagger_units >> 8) + (int)simd * (stagger_units & 255);
+        for (int k = 0; k < delay; k++) __builtin_amdgcn_s_sleep(127);  // 127 * 64 clocks ~ 3.5 us each
     }
     const int g = tid & (LG - 1);
     const int eg = tid / LG;

@@ -758,7 +758,11 @@ void launch_legged_core(raptor_problem& p, const double* dZ, int B, double* dG, 
         const int first = fused_first_round();
         const bool rounds = 2LL * grid >= 3LL * first;
         const int stagger = rounds ? first : 0;
-        const int stagger_units = units_env >= 0 ? units_env : LEG_STAGGER;
+        // per wave slot, per SIMD (RAPTOR_STAGGER_UNITS=u: 4u and u; RAPTOR_STAGGER_AB="a,b": a per wave slot, b per SIMD)
+        static const char* ab_env = std::getenv("RAPTOR_STAGGER_AB");
+        int ua = 4 * (units_env >= 0 ? units_env : LEG_STAGGER), ub = units_env >= 0 ? units_env : LEG_STAGGER;
+        if (ab_env) std::sscanf(ab_env, "%d,%d", &ua, &ub);
+        const int stagger_units = (ua << 8) | (ub & 255);
         if (wide) { if (keven) LEG_LAUNCH_FUSED(32, true); else LEG_LAUNCH_FUSED(32, false); }
         else { if (keven) LEG_LAUNCH_FUSED(16, true); else LEG_LAUNCH_FUSED(16, false); }
 #undef LEG_LAUNCH_FUSED
