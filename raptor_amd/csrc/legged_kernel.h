@@ -272,6 +272,14 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     const int eg = tid / LG;
     // a lane group past the end repeats the last sample-eval (same values to the same addresses): every lane of the wavefront
     // stays active, which the packed table of phase F2 (an entry per lane, read with v_readlane) relies on
+#ifdef LEG_G_TRACE  // measurement build (scripts/fused_trace.py): where a wavefront's life goes -- 100 MHz timestamps left in the torque
+                    // values of the wavefront's first sample
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long trG = 0, trS = 0, trA = 0, trB = 0, trC = 0, trD = 0;
+#define LEG_TR(x) x = __builtin_amdgcn_s_memrealtime();
+#else
+#define LEG_TR(x)
+#endif
     const long long e0 = (long long)blockIdx.x * EPB;  // (uniform; < E by the launch grid)
     const long long e = min(e0 + eg, E - 1);
     double* sl = lds + eg * LL::STRIDE;
@@ -1125,6 +1133,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // ni * K <= 128 (chunks 64.. of a row are structural zeros), n <= 256, two records fit the wavefront's LDS area, a sample has at most
     // LG customized rows.  Pairs of sample-evals are expanded one after the other (LG = 16: two pairs per wavefront).
     if constexpr (FUSE) {
+        LEG_TR(trG)
         constexpr int NH = KEVEN ? 1 : 2;  // distinct actuators a chunk can touch
         const int K = Q->K, n = L.n;
         const int ndyn = ni * K, cpr = n >> 1;
@@ -1214,6 +1223,10 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                         const double w = basis[(size_t)((ia + sx) * 3 + o) * K + kh[h]];
                         W[sx][o][h] = lv[h] ? w : 0.0;  // the structural zeros beyond ni K columns are products with this zero (finite entries: exact)
                     }
+#ifdef LEG_G_TRACE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (rd == 0) { LEG_TR(trS) }
+#endif
 #if defined(LEG_G_PROBE) && LEG_G_PROBE == 2  // measurement build: the phase's set-up alone
             if (tid == 0) JAC[(size_t)ea] = sa[0][tid] + sa[1][5] + W[0][0][0] + W[1][2][1];
             continue;
@@ -1254,6 +1267,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     }
                 }
             }
+            if (rd == 0) { LEG_TR(trA) }
             // -- ConstrainedJointLimits.cpp:59-68: row j is B_k at the joint's own column (independent joint) or P_dep(j, t) B_k
             // (floating-base rows: the P rows parked in LDS; closed-loop rows: Y1 of the joint, still in the registers of its body's lane).
             // The kind of a row is uniform: one scalar branch per row, and the commonest kind -- an independent joint -- touches neither
@@ -1306,6 +1320,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     }
                 }
             }
+            if (rd == 0) { LEG_TR(trB) }
             // -- RectangleSurfaceContactConstraints.cpp:52-93: d(lambda.tail(6)) per unit (q, v, a) of actuator t from the registers
             // of t's column lane (phase F1), lambda from the root body's slot
             {
@@ -1337,6 +1352,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     tail_rows(dst + (size_t)(sx * 7) * n, 7);
                 }
             }
+            if (rd == 0) { LEG_TR(trC) }
             // -- *CustomizedConstraints.cpp (swing-foot / torso rows): row = (ca X[qa] + cb X[qb]) differentiated, X = [swing foot | base].
             // The block is ordered by quantity, then sample: the rows of one quantity at these two samples are adjacent, so the walk is
             // quantity-major -- two quantities x two samples per block, each pair of adjacent rows stored back to back.
@@ -1380,7 +1396,17 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
                     }
                 }
             }
+            if (rd == 0) { LEG_TR(trD) }
         }
+#ifdef LEG_G_TRACE
+        if (tid == 0 && G != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long trE = __builtin_amdgcn_s_memrealtime();
+            double* o = G + rowbase + Q->off_tau + (size_t)i * ni;
+            o[0] = (double)(trG - tr0); o[1] = (double)(trS - trG); o[2] = (double)(trA - trS); o[3] = (double)(trB - trA);
+            o[4] = (double)(trC - trB); o[5] = (double)(trD - trC); o[6] = (double)(trE - trD); o[7] = (double)(trE - tr0);
+        }
+#endif
     }
 }
 
