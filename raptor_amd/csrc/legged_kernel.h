@@ -1122,7 +1122,8 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
 #pragma unroll 1
     for (int idx = 0; idx < nflat; idx++) f2_step(idx, f2_fetch(idx));
 
-    // ---- phase G (FUSE builds): every row of pg_pz but the reset map's, straight from this wavefront's own records.  The expansion is
+    // ---- phase G (FUSE builds): every row of pg_pz but the reset map's, from what this wavefront has on chip (the D blocks in the LDS
+    // slots of the actuators' joints, d(lambda) in the column lanes' registers, the P rows parked in LDS below).  The expansion is
     // bound by the write path and the phases above by fp64 issue: in one kernel the stores of one wavefront drain while the other
     // wavefront of the SIMD computes, which two launches (or two streams: the core kernel holds all of a CU's LDS) never did.
     // With two wavefronts per SIMD nothing hides a chain of dependent LDS look-ups per element (the flat element loop of
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(LEG_BLOCK, 2) void legged_core_kernel(
     // the actuator(s) of the lane's two columns and their Bernstein weights per sample live in registers, a row costs 1-3 LDS reads at
     // constant offsets, a few FMAs and one store.  KEVEN (K even): both columns of a chunk belong to one actuator and share the reads.
     // Host conditions (legged_can_fuse): N even (a pair of sample-evals = consecutive samples of ONE decision vector), n even,
-    // ni * K <= 128 (chunks 64.. of a row are structural zeros), n <= 256, two records fit the wavefront's LDS area, a sample has at most
+    // ni * K <= 128 (chunks 64.. of a row are structural zeros), n <= 256, ni <= 12 and room for the parked P rows, a sample has at most
     // LG customized rows.  Pairs of sample-evals are expanded one after the other (LG = 16: two pairs per wavefront).
     if constexpr (FUSE) {
         LEG_TR(trG)
