@@ -687,8 +687,14 @@ void launch_sphere_rows(raptor_problem& p, const double* dZ, int B, double* dG, 
 // core kernel (values + compact derivative records), then the streaming expansion into pg_pz
 // fused form (round 3): the wide core kernel also writes the torque / joint-limit / contact rows of pg_pz (phase G) -- only the
 // customized block is left for legged_expand_kernel
-bool legged_can_fuse(const raptor_problem& p, const double* dJ) {
+bool legged_can_fuse(const raptor_problem& p, const double* dJ, const long long E) {
     const bool no_fuse = std::getenv("RAPTOR_NO_FUSE") != nullptr;  // read per call: the tests and A/B scripts switch between the two forms
+    // Small batches keep the two-kernel form: a handful of wavefronts expands its rows one after the other, the separate expansion
+    // spreads them over the idle GPU (host-synchronised call, fused / two-kernel: Digit B = 1 174 / 164 us, 128 207 / 198, 256 230 / 236,
+    // 1024 533 / 626; G1 B = 1 90 / 78, 128 102 / 97, 256 110 / 113, 1024 260 / 310 -- scripts/fuse_small_batch_sweep.py).
+    // RAPTOR_FUSE_MIN=<sample-evals> moves the threshold (read per call: the parity test of the fused rows runs at B = 1 .. 5).
+    const char* fm = std::getenv("RAPTOR_FUSE_MIN");
+    if (E < (fm ? std::atoll(fm) : 3072)) return false;
     const int ndyn = p.hleg.ni * p.hleg.K;
     const int LG = p.hleg.nb > 16 ? 32 : 16;
     if (no_fuse || p.htraj.N % 2 != 0 || p.layout.n % 2 != 0 || ((size_t)dJ & 15) != 0) return false;
@@ -819,7 +825,7 @@ void launch_legged(raptor_problem& p, const double* dZ, int B, double* dG, doubl
     // kernels to run beside the core kernel and lose ~10 us at every size (one G1 problem: 87.6 us forked, 77.5 us on one stream).
     static const long long fork_max = std::getenv("RAPTOR_FORK_MAX") ? std::atoll(std::getenv("RAPTOR_FORK_MAX")) : 16384;
     static const bool fork_forced = std::getenv("RAPTOR_FORK_MAX") != nullptr;  // experiments: also under per-kernel timing
-    const bool fused = jac && B > 0 && legged_can_fuse(p, dJ);
+    const bool fused = jac && B > 0 && legged_can_fuse(p, dJ, E);
     double* const dJf = fused ? dJ : nullptr;
     const bool fork = !no_fork && (p.has_digit || fork_forced) && p.period_rows && jac && B > 0 && E <= fork_max && (between == nullptr || fork_forced);
     if (fork) {

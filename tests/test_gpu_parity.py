@@ -569,7 +569,8 @@ def test_legged_sample_counts(oracle, hip, which, N):
 
 @pytest.mark.parametrize("which,N,B", [("g1", 14, 5), ("talos", 2, 3), ("g1", 16, 2), ("digit", 14, 5), ("digit", 2, 1), ("digit", 16, 3)])
 def test_legged_fused_rows_against_two_kernel_form(oracle, hip, which, N, B, monkeypatch):
-    """Even sample counts take the fused form (the core kernel writes the pg_pz rows of its own sample-evals); RAPTOR_NO_FUSE=1 (read
+    """Even sample counts and at least 3072 sample-evals (RAPTOR_FUSE_MIN, forced to 0 here) take the fused form (the core kernel
+    writes the pg_pz rows of its own sample-evals); RAPTOR_NO_FUSE=1 (read
     per call) keeps the record kernel + legged_expand_kernel.  Both forms against the oracle and against each other, on a Jacobian
     buffer pre-filled with NaN (every entry must be written, structural zeros included), with batches that leave the last wavefront
     of the LG = 16 kernel half empty (E = B N = 2 mod 4)."""
@@ -590,6 +591,7 @@ def test_legged_fused_rows_against_two_kernel_form(oracle, hip, which, N, B, mon
     Zd = torch.from_numpy(Z).cuda()
     st = torch.cuda.current_stream().cuda_stream
     out = {}
+    monkeypatch.setenv("RAPTOR_FUSE_MIN", "0")  # batches this small take the two-kernel form by default
     for form in ("fused", "two_kernel"):
         if form == "two_kernel":
             monkeypatch.setenv("RAPTOR_NO_FUSE", "1")
