@@ -617,6 +617,39 @@ def test_legged_fused_rows_against_two_kernel_form(oracle, hip, which, N, B, mon
     assert np.max(np.abs(Jf - Jt)) <= 1e-13 * max(1.0, np.max(np.abs(Jt)))
 
 
+@pytest.mark.parametrize("which,B", [("digit", 512), ("g1", 4096)])
+def test_legged_fused_rows_large_batch(hip, which, B, monkeypatch):
+    """The launch forms only large batches take -- staggered start of the first round (more than 1.5 rounds of wavefronts), seven
+    workgroups per CU for the LG = 16 instance (six rounds or more) -- against the two-kernel form on the device: same g, same
+    structural zeros, pg_pz to 1e-13."""
+    import torch
+
+    keep = []
+    if which == "digit":
+        ph, _, _ = H.digit_problem(hip, keep, N=14, customized=True, periodic=True)
+    else:
+        ph, _, _ = H.legged_problem(hip, which, keep, N=14, customized=True, periodic=True)
+    g = torch.Generator(device="cpu").manual_seed(20250602)
+    Z = (0.1 * (torch.rand(B, ph.n, generator=g, dtype=torch.float64) * 2 - 1)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for form in ("fused", "two_kernel"):
+        if form == "two_kernel":
+            monkeypatch.setenv("RAPTOR_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("RAPTOR_NO_FUSE", raising=False)
+        G = torch.full((B, ph.m), float("nan"), dtype=torch.float64, device="cuda")
+        J = torch.full((B, ph.m, ph.n), float("nan"), dtype=torch.float64, device="cuda")
+        ph.eval_device(Z.data_ptr(), B, A.EVAL_G | A.EVAL_JAC, G.data_ptr(), J.data_ptr(), st)
+        torch.cuda.synchronize()
+        out[form] = (G, J)
+    monkeypatch.delenv("RAPTOR_NO_FUSE", raising=False)
+    (Gf, Jf), (Gt, Jt) = out["fused"], out["two_kernel"]
+    assert torch.isfinite(Jf).all() and torch.equal(Gf, Gt)
+    assert torch.equal(Jf == 0.0, Jt == 0.0)
+    assert (Jf - Jt).abs().max().item() <= 1e-13 * max(1.0, Jt.abs().max().item())
+
+
 def test_digit_eval_g_and_jac(oracle, hip):
     """eval_g / eval_jac_g of DigitSingleStepOptimizer's first three blocks at the example's size (N = 14, degree 5)."""
     keep = []
